@@ -1,0 +1,130 @@
+/* whisper_mi.h — C-ABI of libwhispermi.so: the MI355X (gfx950) replacement for the hot path of
+ * antonvice/whisper.Mojo.  Plain C, no torch / C++ types cross this boundary.
+ *
+ * The reference has no FFI of its own (it is one Mojo program); the surface below is what a Mojo
+ * `sys.ffi.DLHandle` (or Python ctypes) binding of that program would bind, one entry per reference
+ * function it replaces (file:line relative to the reference repo).  INTEGRATION.md shows the Mojo stub.
+ *
+ * Conventions: every function returns 0 on success or a negative WM_E_* code and never throws;
+ * wm_last_error() gives the message (thread-local).  Opaque handles own all device memory; every host
+ * buffer is caller-owned and caller-sized.  One wm_model lives on one GPU; calls on one handle must be
+ * serialised by the caller (the reference is single-caller too: whisper.mojo:184 takes self immutably and
+ * builds its cache locally).  Different handles (other GPUs / processes) are independent.
+ */
+#ifndef WHISPER_MI_H
+#define WHISPER_MI_H
+#include <stddef.h>
+#include <stdint.h>
+#include "wm_synth.h" /* wm_dims */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { WM_OK = 0, WM_E_ARG = -1, WM_E_SIZE = -2, WM_E_IO = -3, WM_E_HIP = -4, WM_E_STATE = -5 };
+enum { WM_F32 = 0, WM_BF16 = 1, WM_F16 = 2 };
+enum { WM_GELU_TANH = 0 /* whisper_tensor.mojo:288-308 */, WM_GELU_ERF = 1 /* HF */ };
+enum { WM_POS_REF = 0 /* start_pos = current_len-1, whisper.mojo:217 */, WM_POS_HF = 1 /* = current_len */ };
+
+/* Replaces WhisperConfig (whisper.mojo:15-31) + config.mojo:4-17.  dims.d_model / dims.n_heads must be 64
+ * (layers.mojo:190-198 hard-codes a 64-wide head). */
+typedef struct {
+    wm_dims dims;
+    int gelu_mode;     /* WM_GELU_* */
+    int compute_dtype; /* WM_F32: exact fp32 MFMA everywhere.  WM_BF16 / WM_F16: GEMM operands (weights and
+                          the activations fed to them) are 16-bit, accumulation / LayerNorm / softmax /
+                          residual stream stay fp32 */
+    int kv_dtype;      /* storage type of the self- and cross-attention K/V cache: WM_F32 or compute_dtype */
+    int max_batch;     /* largest B any later call will pass (arena sizing) */
+} wm_config;
+
+/* Replaces the literals in Whisper.transcribe (whisper.mojo:187-191 prompt, :206 eot, :205 loop bound). */
+typedef struct {
+    const int32_t* prompt;
+    int n_prompt;
+    int eot;
+    int max_loop;   /* reference: 195 -> at most n_prompt + 1 + 195 ids per utterance */
+    int pos_mode;   /* WM_POS_* */
+    int ignore_eot; /* != 0: "fixed" mode — never stop early (bench) */
+} wm_decode_opts;
+
+typedef struct wm_model wm_model;
+typedef struct wm_state wm_state;
+
+const char* wm_last_error(void);
+
+/* ---- WeightLoader(filename) + Whisper() + Whisper.load(loader)   loader.mojo:10-27, whisper.mojo:175-182 ----
+ * path: the reference's headerless little-endian fp32 file (order of export_weights.py:19-90).  Unlike the
+ * reference (loader.mojo:21-27 reads past the end silently) the byte size is validated: WM_E_SIZE. */
+int wm_model_load(const char* path, const wm_config* cfg, int device, wm_model** out);
+/* Same from a host image of n_floats fp32 values. */
+int wm_model_load_memory(const float* weights, size_t n_floats, const wm_config* cfg, int device, wm_model** out);
+void wm_model_free(wm_model* m);
+size_t wm_weight_count(const wm_dims* dims);
+
+/* ---- KVCache(n_layers, d_model, 448)   layers.mojo:55-63 — one per batch of B utterances ------------------- */
+int wm_state_new(wm_model* m, int batch, wm_state** out);
+int wm_state_reset(wm_state* s); /* current_len = 0, has_cross = false */
+void wm_state_free(wm_state* s);
+int wm_state_len(const wm_state* s); /* LayerCache.current_len (layers.mojo:18) */
+
+/* ---- WhisperEncoder.forward(mel) -> Tensor   whisper.mojo:71-99 ---------------------------------------------
+ * mel: [B, n_mels, 2*n_audio_ctx] fp32 row-major (sample_input.bin layout, main.mojo:23-27); host pointer, or
+ * a device pointer on the model's GPU when mel_on_device != 0.  Resets `s`, keeps the encoder output inside it
+ * for the decoder, and (if enc_out != NULL) copies it to host as [B, n_audio_ctx, d_model] fp32. */
+int wm_encode(wm_model* m, wm_state* s, const float* mel, int mel_on_device, int B, float* enc_out);
+/* Stage-level tests: inject an encoder output [B, n_audio_ctx, d_model] (host) instead of running the encoder. */
+int wm_state_set_encoder_output(wm_model* m, wm_state* s, const float* enc_out, int B);
+
+/* ---- WhisperDecoder.forward(tokens, enc_out, cache, use_cache=True, start_pos) -> logits  whisper.mojo:130-167 --
+ * tokens [B, q_len] (host), start_pos [B] (host; the reference passes one Int — per-utterance here; it stays a
+ * CALLER argument so that the position quirk of whisper.mojo:217 lives in the host loop).  Appends q_len
+ * positions to the cache (layers.mojo:140-143); computes the cross K/V on first use (layers.mojo:150-154).
+ * logits: NULL or host [B, vocab] for the last position; next: NULL or host [B] = argmax (lowest index wins,
+ * whisper_tensor.mojo:431-439). */
+int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, int q_len, const int32_t* start_pos,
+                   float* logits, int32_t* next);
+
+/* ---- Whisper.transcribe(mel) -> List[Int]   whisper.mojo:184-223 ------------------------------------------
+ * tokens_out: host [B, n_prompt + 1 + max_loop]; row b holds prompt + generated ids (incl. the trailing eot when
+ * hit), exactly the reference's list; n_tokens[b] = its length.  The whole greedy loop runs on the GPU (token
+ * feedback never visits the host); the host only polls "all finished" every few steps. */
+int wm_transcribe(wm_model* m, const float* mel, int mel_on_device, int B, const wm_decode_opts* opts,
+                  int32_t* tokens_out, int32_t* n_tokens);
+
+/* ---- op-level entry points (host pointers; known-answer tests only) ------------------------------------------
+ * Same argument meaning as the reference ops: out-param first, caller-allocated. */
+/* matmul(C, A, B, bias)  whisper_tensor.mojo:151-246 : C[M,N] = A[M,K]·B[N,K]ᵀ (+bias[N], may be NULL).
+ * dtype selects the operand rounding (WM_F32 exact).  Requires K % 32 == 0. */
+int wm_op_matmul_nt(float* C, const float* A, const float* B, const float* bias, int M, int N, int K, int dtype);
+/* layer_norm(out, inp, gamma, beta, eps)  whisper_tensor.mojo:249-285 (one-pass variance). cols % 64 == 0 */
+int wm_op_layer_norm(float* out, const float* inp, const float* gamma, const float* beta, int rows, int cols,
+                     float eps);
+/* gelu(t) in place  whisper_tensor.mojo:288-308 (mode WM_GELU_TANH) */
+int wm_op_gelu(float* t, size_t n, int mode);
+/* softmax(t) rows in place  whisper_tensor.mojo:311-355 */
+int wm_op_softmax_rows(float* t, int rows, int cols);
+/* conv1d(out, inp, weight, bias, stride, padding, out_T)  whisper_tensor.mojo:367-428; K=3, padding=1.
+ * inp [C_in, L_in]; weight in the ORIGINAL [C_out, C_in, 3] file layout (the transpose of
+ * whisper_tensor.mojo:358-364 is internal); out [C_out, L_out] or [L_out, C_out] when out_T. */
+int wm_op_conv1d_k3(float* out, const float* inp, const float* weight, const float* bias, int C_in, int L_in,
+                    int C_out, int stride, int out_T, int dtype);
+/* argmax(t)  whisper_tensor.mojo:431-439 */
+int wm_op_argmax(const float* t, int n, int32_t* idx);
+
+/* ---- measurement helpers (bench.py) ----------------------------------------------------------------------------- */
+enum { WM_KERNEL_CROSS_ATTN = 0, WM_KERNEL_DECODE_STEP = 1, WM_KERNEL_ENCODER = 2 };
+/* Launches `reps` instances of the named kernel / stage on the library's stream between two HIP events and
+ * returns the average duration in microseconds.  State must have been encoded (cross K/V present). */
+int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, float* avg_us);
+/* Algorithmic HBM bytes one launch of `which` moves for state `s` (SURVEY §8d formulas). */
+int wm_bench_bytes(wm_model* m, wm_state* s, int which, double* bytes);
+
+/* Synthetic weights / mels (include/wm_synth.h) exported for hosts that cannot include the header. */
+size_t wm_synth_weights(const wm_dims* dims, uint64_t seed, float* out);
+void wm_synth_mel_host(uint64_t seed, int n_mels, int n_frames, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

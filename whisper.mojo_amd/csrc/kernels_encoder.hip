@@ -1,0 +1,326 @@
+// kernels_encoder.hip — the dense (MFMA-bound) half of the path: conv stem as implicit GEMM, the 1500-row
+// projections / MLP, fused flash-style encoder attention, LayerNorm rows.  gfx950 only.
+//
+// Replaces (reference file:line): conv1d whisper_tensor.mojo:367-428 (+gelu :288-308, +pos add whisper.mojo:83-89),
+// matmul_384x384/_384x1536/_1536x384 whisper_tensor.mojo:74-122, matmul_Q_K/_S_V + softmax + head gather/scatter
+// layers.mojo:273-342, layer_norm whisper_tensor.mojo:249-285, residual adds layers.mojo:457-461,483-487,513-517.
+#include "wm_kernels.h"
+
+namespace wm {
+
+// ------------------------------------------------------------------------------------------------------------
+// mel [B][C][L] fp32 (channel-major, sample_input.bin layout) -> token-major, zero-padded [B][L+2][Cp] T.
+// Row t+1 holds frame t; rows 0 and L+1 are the conv zero padding (the reference skips out-of-range taps,
+// whisper_tensor.mojo:405,422); channels >= C are zero so the implicit-GEMM K is a multiple of 32.
+// Replaces the input transpose of conv1d (whisper_tensor.mojo:383-388).
+template <typename T>
+__global__ __launch_bounds__(256) void mel_transpose_pad_kernel(const float* __restrict__ mel, T* __restrict__ out,
+                                                                int C, int L, int Cp) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const float* src = mel + (size_t)b * C * L;
+    T* dst = out + (size_t)b * (L + 2) * Cp;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        int c = i >> 6, t = i & 63;
+        float v = 0.f;
+        if (c0 + c < C && t0 + t < L) v = src[(size_t)(c0 + c) * L + t0 + t];
+        tile[c][t] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        int t = i >> 6, c = i & 63;
+        if (c0 + c < Cp && t0 + t < L) dst[(size_t)(t0 + t + 1) * Cp + c0 + c] = from_f32<T>(tile[c][t]);
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        for (int c = threadIdx.x; c < Cp; c += 256) {
+            dst[c] = from_f32<T>(0.f);
+            dst[(size_t)(L + 1) * Cp + c] = from_f32<T>(0.f);
+        }
+    }
+}
+
+template <typename T>
+void launch_mel_transpose_pad(const float* mel, void* out, int B, int C, int L, int Cp, hipStream_t st) {
+    dim3 grid((L + 63) / 64, (Cp + 63) / 64, B);
+    hipLaunchKernelGGL(mel_transpose_pad_kernel<T>, grid, dim3(256), 0, st, mel, (T*)out, C, L, Cp);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// C[M,N] = A[M,K]·W[N,K]ᵀ with a fused epilogue.  Both operands are K-contiguous ("NT"), which is what the
+// reference's HF-layout weights give (whisper_tensor.mojo:151: B is [out,in]) and what MFMA fragments want.
+// 128x128 tile / 256 threads; wave (wm,wn) owns 64x64 = 4x4 MFMA 16x16 accumulators; K step 32.
+// Computed as Cᵀ tiles (A-operand = W fragment) so that each lane ends up with 4 CONSECUTIVE output columns of one
+// row: 16-byte epilogue loads/stores.
+// An implicit-GEMM conv is the same kernel with overlapping A rows (lda = stride*C_in over the padded token-major
+// input, K = 3*C_in): row t of A is the contiguous window x[t*stride-1 .. t*stride+1][:].
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * 128 + wm * 64, n0 = blockIdx.x * 128 + wn * 64;
+    const T* A = (const T*)p.A + (size_t)blockIdx.z * p.strideA;
+    const T* W = (const T*)p.W;
+    const T* ap[4];
+    const T* wp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ap[i] = A + (size_t)(m0 + i * 16 + r16) * p.lda + g * 8;
+        wp[i] = W + (size_t)(n0 + i * 16 + r16) * p.ldw + g * 8;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < p.K; k0 += 32) {
+        Frag<T> a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = load_frag<T>(ap[i] + k0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = load_frag<T>(wp[j] + k0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = mma32(b[j], a[i], acc[j][i]);
+    }
+
+    // epilogue: acc[j][i][r] = C[m0 + 16i + r16][n0 + 16j + 4g + r]
+    TO* Cb = (TO*)p.C + (size_t)blockIdx.z * p.strideC;
+    const float* Rb = p.residual ? p.residual + (size_t)blockIdx.z * p.strideR : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + i * 16 + r16;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + j * 16 + g * 4;
+            f32x4 v = acc[j][i];
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], p.gelu_mode);
+            }
+            if (p.pos) v += *reinterpret_cast<const f32x4*>(p.pos + (size_t)m * p.N + n);
+            if (Rb) v += *reinterpret_cast<const f32x4*>(Rb + (size_t)m * p.ldr + n);
+            size_t off;
+            if (p.group_n > 0)
+                off = (size_t)(n / p.group_n) * p.group_stride + (size_t)m * p.ldc + (n % p.group_n);
+            else
+                off = (size_t)m * p.ldc + n;
+            if constexpr (sizeof(TO) == 4) {
+                *reinterpret_cast<f32x4*>((float*)Cb + off) = v;
+            } else {
+                typedef __attribute__((ext_vector_type(4))) TO to4;
+                to4 o = {from_f32<TO>(v[0]), from_f32<TO>(v[1]), from_f32<TO>(v[2]), from_f32<TO>(v[3])};
+                *reinterpret_cast<to4*>(Cb + off) = o;
+            }
+        }
+    }
+}
+
+template <typename T, typename TO> void launch_gemm_nt(const GemmParams& p, int batch, hipStream_t st) {
+    dim3 grid(p.N / 128, (p.M + 127) / 128, batch);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, TO>), grid, dim3(256), 0, st, p);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm over rows of `cols` fp32 (whisper_tensor.mojo:249-285: one-pass variance E[x²]-mean², eps inside the
+// sqrt).  One wave per row, wave64 butterfly for Σx and Σx².  Writes the GEMM-operand copy (T) and/or an fp32 copy.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, T* __restrict__ out_t,
+                                                             float* __restrict__ out_f, int rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * cols;
+    float v[16];  // cols <= 1024
+    float s = 0.f, q = 0.f;
+    const int n = cols >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < n) {
+            v[i] = xr[lane + 64 * i];
+            s += v[i];
+            q += v[i] * v[i];
+        }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    const float mean = s / (float)cols;
+    const float var = (q / (float)cols) - (mean * mean);
+    const float inv_std = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < n) {
+            const int c = lane + 64 * i;
+            float y = (v[i] - mean) * inv_std * gamma[c] + beta[c];
+            if (out_t) out_t[(size_t)row * cols + c] = from_f32<T>(y);
+            if (out_f) out_f[(size_t)row * cols + c] = y;
+        }
+}
+
+template <typename T>
+void launch_layernorm_rows(const float* x, const float* gamma, const float* beta, void* out_t, float* out_f, int rows,
+                           int cols, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(layernorm_rows_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, st, x, gamma, beta, (T*)out_t, out_f,
+                       rows, cols, eps);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Fused encoder self-attention (no mask): O = softmax(Q·Kᵀ·scale)·V per (utterance, head), never materialising the
+// n_ctx x n_ctx scores the reference allocates per head (layers.mojo:293).  Scale is applied AFTER the dot product
+// as the reference does (layers.mojo:306-308).
+//
+// Workgroup = 4 waves = 64 query rows (16 per wave) of one (b, h); K/V stream through LDS in 64-key tiles.
+//   Sᵀ = K·Qᵀ  : A-operand = K fragment (rows = keys), B-operand = Q fragment (cols = q)  ->  lane (q = lane&15,
+//                g = lane>>4) holds S[q][16kb + 4g + r]: the softmax row statistics are per-lane + a 4-lane reduce.
+//   Oᵀ = Vᵀ·Pᵀ : the 8 probabilities a lane holds for one 32-key chunk ARE the B-operand fragment (k order permuted:
+//                element j of group g <-> key 32c + 16(j>>2) + 4g + (j&3)); V is staged TRANSPOSED in LDS in that
+//                same key order so the A-operand fragment is one contiguous 8-element read.  No LDS round trip for P,
+//                and the O accumulator has q on the lane too, so rescaling needs no cross-lane traffic.
+template <typename T> struct AttnLds {
+    static constexpr int PAD = 16 / sizeof(T);
+    static constexpr int PITCH = 64 + PAD;  // 144 B (16-bit) / 272 B (fp32): 16-lane b128 reads hit 16 distinct slots
+};
+
+template <typename T, bool FAST>
+__global__ __launch_bounds__(256) void flash_attn_enc_kernel(const T* __restrict__ qkv, T* __restrict__ out, int n_ctx,
+                                                             int d_model, float scale) {
+    constexpr int PITCH = AttnLds<T>::PITCH;
+    __shared__ __attribute__((aligned(16))) T Ks[64 * PITCH];
+    __shared__ __attribute__((aligned(16))) T Vt[64 * PITCH];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const size_t ld = (size_t)3 * d_model;
+    const T* base = qkv + (size_t)b * n_ctx * ld;
+    const int q_row = blockIdx.x * 64 + wid * 16 + r16;
+    const int q_ld = q_row < n_ctx ? q_row : n_ctx - 1;
+    Frag<T> qf[2];
+#pragma unroll
+    for (int dc = 0; dc < 2; ++dc) qf[dc] = load_frag<T>(base + (size_t)q_ld * ld + h * 64 + dc * 32 + g * 8);
+
+    f32x4 o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e30f, l_run = 0.f;
+
+    const T* kbase = base + d_model + h * 64;
+    const T* vbase = base + 2 * d_model + h * 64;
+    const int n_tiles = (n_ctx + 63) / 64;
+    for (int t = 0; t < n_tiles; ++t) {
+        const int key0 = t * 64;
+        __syncthreads();  // previous tile fully consumed
+        // stage K (row-major) and V (transposed, permuted key order): 512 chunks of 8 elements each
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int chunk = threadIdx.x + it * 256;
+            const int key = chunk >> 3, dch = chunk & 7;
+            int krow = key0 + key;
+            krow = krow < n_ctx ? krow : n_ctx - 1;
+            Frag<T> kf = load_frag<T>(kbase + (size_t)krow * ld + dch * 8);
+            Frag<T> vf = load_frag<T>(vbase + (size_t)krow * ld + dch * 8);
+            if constexpr (sizeof(T) == 2) {
+                *reinterpret_cast<decltype(kf.v)*>(&Ks[key * PITCH + dch * 8]) = kf.v;
+            } else {
+                *reinterpret_cast<f32x4*>(&Ks[key * PITCH + dch * 8]) = f32x4{kf.v[0], kf.v[1], kf.v[2], kf.v[3]};
+                *reinterpret_cast<f32x4*>(&Ks[key * PITCH + dch * 8 + 4]) = f32x4{kf.v[4], kf.v[5], kf.v[6], kf.v[7]};
+            }
+            const int c = key >> 5, kk = key & 31;
+            const int pos = 32 * c + 8 * ((kk >> 2) & 3) + 4 * (kk >> 4) + (kk & 3);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Vt[(dch * 8 + e) * PITCH + pos] = vf.v[e];
+        }
+        __syncthreads();
+
+        // Sᵀ tile: 4 key blocks x 2 dim chunks
+        f32x4 s[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dc = 0; dc < 2; ++dc) {
+                Frag<T> kf = load_frag<T>(&Ks[(kb * 16 + r16) * PITCH + dc * 32 + g * 8]);
+                s[kb] = mma32(kf, qf[dc], s[kb]);
+            }
+        }
+        float tmax = -1e30f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = s[kb][r] * scale;
+                if (key0 + kb * 16 + g * 4 + r >= n_ctx) v = -1e30f;
+                s[kb][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = FAST ? __expf(m_run - m_new) : expf(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        float pv[2][8];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pe = FAST ? __expf(s[kb][r] - m_new) : expf(s[kb][r] - m_new);
+                psum += pe;
+                pv[kb >> 1][(kb & 1) * 4 + r] = pe;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) o[db] *= alpha;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            Frag<T> pf = make_frag<T>(pv[c]);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                Frag<T> vf = load_frag<T>(&Vt[(db * 16 + r16) * PITCH + c * 32 + g * 8]);
+                o[db] = mma32(vf, pf, o[db]);
+            }
+        }
+    }
+    float l = l_run;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (q_row < n_ctx) {
+        T* orow = out + ((size_t)b * n_ctx + q_row) * d_model + h * 64;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            typedef __attribute__((ext_vector_type(4))) T t4;
+            t4 ov = {from_f32<T>(o[db][0] * inv), from_f32<T>(o[db][1] * inv), from_f32<T>(o[db][2] * inv),
+                     from_f32<T>(o[db][3] * inv)};
+            *reinterpret_cast<t4*>(orow + db * 16 + g * 4) = ov;
+        }
+    }
+}
+
+template <typename T>
+void launch_flash_attn_enc(const void* qkv, void* out, int B, int H, int n_ctx, float scale, hipStream_t st) {
+    dim3 grid((n_ctx + 63) / 64, H, B);
+    constexpr bool FAST = sizeof(T) == 2;
+    hipLaunchKernelGGL((flash_attn_enc_kernel<T, FAST>), grid, dim3(256), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64,
+                       scale);
+}
+
+// ---- explicit instantiations --------------------------------------------------------------------------------
+#define WM_INST_T(T)                                                                                          \
+    template void launch_mel_transpose_pad<T>(const float*, void*, int, int, int, int, hipStream_t);          \
+    template void launch_layernorm_rows<T>(const float*, const float*, const float*, void*, float*, int, int, \
+                                           float, hipStream_t);                                               \
+    template void launch_flash_attn_enc<T>(const void*, void*, int, int, int, float, hipStream_t);
+WM_INST_T(float)
+WM_INST_T(bf16)
+WM_INST_T(f16)
+template void launch_gemm_nt<float, float>(const GemmParams&, int, hipStream_t);
+template void launch_gemm_nt<bf16, float>(const GemmParams&, int, hipStream_t);
+template void launch_gemm_nt<bf16, bf16>(const GemmParams&, int, hipStream_t);
+template void launch_gemm_nt<f16, float>(const GemmParams&, int, hipStream_t);
+template void launch_gemm_nt<f16, f16>(const GemmParams&, int, hipStream_t);
+
+}  // namespace wm

@@ -1,0 +1,1151 @@
+// whisper_mi.cpp — host runtime behind the C-ABI of include/whisper_mi.h (compiled with hipcc).
+//
+// One wm_model per GPU: weights resident in HBM in kernel-friendly layouts, one HIP stream, no per-op allocation
+// (the reference zero-fills a fresh heap Tensor for every intermediate, whisper_tensor.mojo:17-23; here every
+// buffer belongs to a preallocated per-state arena).  The greedy loop of Whisper.transcribe (whisper.mojo:184-223)
+// runs with the token feedback entirely on the device.
+#include "../../include/whisper_mi.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "wm_kernels.h"
+
+using namespace wm;
+
+// ------------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return fail(WM_E_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define WMCHK(expr)            \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+extern "C" const char* wm_last_error(void) { return g_err.c_str(); }
+
+static size_t dt_size(int dt) { return dt == WM_F32 ? 4 : 2; }
+static inline uint16_t f32_to_bf16_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline uint16_t f32_to_f16_host(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n, bool zero = false) {
+        bytes = n ? n : 16;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return fail(WM_E_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        if (zero) {
+            e = hipMemset(p, 0, bytes);
+            if (e != hipSuccess) return fail(WM_E_HIP, "hipMemset: %s", hipGetErrorString(e));
+        }
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+// host fp32 -> device buffer in dtype dt
+static int upload(DevBuf& b, const float* h, size_t n, int dt) {
+    WMCHK(b.alloc(n * dt_size(dt)));
+    if (dt == WM_F32) {
+        HIPCHK(hipMemcpy(b.p, h, n * 4, hipMemcpyHostToDevice));
+    } else {
+        std::vector<uint16_t> tmp(n);
+        if (dt == WM_BF16)
+            for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16_host(h[i]);
+        else
+            for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_f16_host(h[i]);
+        HIPCHK(hipMemcpy(b.p, tmp.data(), n * 2, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+struct EncLayer {
+    DevBuf qkv_w, qkv_b, o_w, o_b, ln1_g, ln1_b, fc1_w, fc1_b, fc2_w, fc2_b, ln2_g, ln2_b;
+};
+struct DecLayer {
+    DevBuf sqkv_w, sqkv_b, so_w, so_b, ln1_g, ln1_b, cq_w, cq_b, co_w, co_b, lnx_g, lnx_b, fc1_w, fc1_b, fc2_w, fc2_b, ln2_g,
+        ln2_b;
+};
+
+struct wm_model {
+    wm_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int Cp = 0;  // mel channels padded to a multiple of 32 (implicit-GEMM K)
+    int Vpad = 0;
+    int enc_chunk = 8;  // utterances per encoder pass (activations stay Infinity-Cache resident)
+    DevBuf conv1_w, conv1_b, conv2_w, conv2_b, enc_pos;
+    std::vector<EncLayer> enc;
+    DevBuf enc_ln_g, enc_ln_b;
+    DevBuf tok_emb_f, tok_emb_t, dec_pos;
+    std::vector<DecLayer> dec;
+    DevBuf dec_ln_g, dec_ln_b;
+    DevBuf cross_kv_w, cross_kv_b;  // [L*2*d][d] rows: layer-major, K then V
+    wm_state* cached = nullptr;
+};
+
+struct wm_state {
+    wm_model* m = nullptr;
+    int B = 0;
+    int Bc = 0;  // encoder chunk
+    int nsplit = 1;
+    int out_stride = 0;
+    bool has_enc = false, has_cross = false;
+    int host_len = 0;
+    // encoder arena (sized for Bc utterances)
+    DevBuf mel_dev, mel_t, h1, x, xn, qkv, ao, hid, enc_t;
+    DevBuf enc_f;            // [B*n_ctx][d] fp32
+    DevBuf cross_kv;         // [L][2][B][n_ctx][d] kv dtype
+    DevBuf self_kv;          // [L][2][B][n_text_ctx][d]
+    // decode arena
+    DevBuf dx, dq, dattn, dhid, part_o, part_ml, logits, tok, pos, ctl, out_tokens, n_tokens, finished;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+#define DISPATCH_DT(dt, T, ...)              \
+    do {                                     \
+        if ((dt) == WM_F32) {                \
+            typedef float T;                 \
+            __VA_ARGS__;                     \
+        } else if ((dt) == WM_BF16) {        \
+            typedef wm::bf16 T;              \
+            __VA_ARGS__;                     \
+        } else {                             \
+            typedef wm::f16 T;               \
+            __VA_ARGS__;                     \
+        }                                    \
+    } while (0)
+
+static void gemm_dispatch(int dt_in, int dt_out, const GemmParams& p, int batch, hipStream_t st) {
+    if (dt_in == WM_F32) {
+        launch_gemm_nt<float, float>(p, batch, st);
+    } else if (dt_in == WM_BF16) {
+        if (dt_out == WM_F32)
+            launch_gemm_nt<bf16, float>(p, batch, st);
+        else
+            launch_gemm_nt<bf16, bf16>(p, batch, st);
+    } else {
+        if (dt_out == WM_F32)
+            launch_gemm_nt<f16, float>(p, batch, st);
+        else
+            launch_gemm_nt<f16, f16>(p, batch, st);
+    }
+}
+
+extern "C" size_t wm_weight_count(const wm_dims* c) { return wm_synth_count(c); }
+extern "C" size_t wm_synth_weights(const wm_dims* dims, uint64_t seed, float* out) { return wm_synth_fill(dims, seed, out); }
+extern "C" void wm_synth_mel_host(uint64_t seed, int n_mels, int n_frames, float* out) {
+    wm_synth_mel(seed, n_mels, n_frames, out);
+}
+
+static int check_cfg(const wm_config* c) {
+    const wm_dims& d = c->dims;
+    if (d.d_model <= 0 || d.n_heads <= 0 || d.d_model != d.n_heads * 64)
+        return fail(WM_E_ARG, "d_model must equal n_heads*64 (got %d, %d)", d.d_model, d.n_heads);
+    if (d.n_heads > 8) return fail(WM_E_ARG, "n_heads > 8 not supported");
+    if (d.d_model % 128 || d.ffn % 128) return fail(WM_E_ARG, "d_model and ffn must be multiples of 128");
+    if ((d.n_layers * 2 * d.d_model) % 128) return fail(WM_E_ARG, "n_layers*2*d_model must be a multiple of 128");
+    if (d.n_text_ctx > 512) return fail(WM_E_ARG, "n_text_ctx > 512 not supported");
+    if (d.n_mels <= 0 || d.n_audio_ctx <= 0 || d.vocab <= 0 || d.n_layers <= 0) return fail(WM_E_ARG, "bad dims");
+    if (c->compute_dtype < 0 || c->compute_dtype > 2) return fail(WM_E_ARG, "bad compute_dtype");
+    if (!(c->kv_dtype == WM_F32 || c->kv_dtype == c->compute_dtype))
+        return fail(WM_E_ARG, "kv_dtype must be WM_F32 or equal compute_dtype");
+    if (c->max_batch <= 0) return fail(WM_E_ARG, "max_batch must be > 0");
+    if (c->gelu_mode != 0 && c->gelu_mode != 1) return fail(WM_E_ARG, "bad gelu_mode");
+    return 0;
+}
+
+// ---- model load: loader.mojo:10-27 + whisper.mojo:60-69,122-128 + layers.mojo:96-103,418-433 -------------------
+struct Reader {
+    const float* p;
+    size_t off = 0;
+    const float* take(size_t n) {
+        const float* r = p + off;
+        off += n;
+        return r;
+    }
+};
+struct AttnW {
+    const float *q_w, *q_b, *k_w, *v_w, *v_b, *o_w, *o_b;
+};
+static AttnW read_attn(Reader& r, size_t d) {
+    AttnW a;
+    a.q_w = r.take(d * d);
+    a.q_b = r.take(d);
+    a.k_w = r.take(d * d);
+    a.v_w = r.take(d * d);
+    a.v_b = r.take(d);
+    a.o_w = r.take(d * d);
+    a.o_b = r.take(d);
+    return a;
+}
+// [co][ci][3] -> [co][3][ci_pad]   (transpose_conv_weights, whisper_tensor.mojo:358-364, plus channel padding)
+static std::vector<float> conv_relayout(const float* w, int co, int ci, int cip) {
+    std::vector<float> o((size_t)co * 3 * cip, 0.f);
+    for (int a = 0; a < co; ++a)
+        for (int c = 0; c < ci; ++c)
+            for (int k = 0; k < 3; ++k) o[((size_t)a * 3 + k) * cip + c] = w[(size_t)a * ci * 3 + (size_t)c * 3 + k];
+    return o;
+}
+
+extern "C" void wm_state_free(wm_state* s);
+
+extern "C" void wm_model_free(wm_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->cached) wm_state_free(m->cached);
+    DevBuf* top[] = {&m->conv1_w, &m->conv1_b, &m->conv2_w, &m->conv2_b, &m->enc_pos, &m->enc_ln_g, &m->enc_ln_b,
+                     &m->tok_emb_f, &m->tok_emb_t, &m->dec_pos, &m->dec_ln_g, &m->dec_ln_b, &m->cross_kv_w, &m->cross_kv_b};
+    for (DevBuf* b : top) b->release();
+    for (EncLayer& l : m->enc) {
+        DevBuf* bs[] = {&l.qkv_w, &l.qkv_b, &l.o_w, &l.o_b, &l.ln1_g, &l.ln1_b, &l.fc1_w, &l.fc1_b, &l.fc2_w, &l.fc2_b, &l.ln2_g, &l.ln2_b};
+        for (DevBuf* b : bs) b->release();
+    }
+    for (DecLayer& l : m->dec) {
+        DevBuf* bs[] = {&l.sqkv_w, &l.sqkv_b, &l.so_w, &l.so_b, &l.ln1_g, &l.ln1_b, &l.cq_w, &l.cq_b, &l.co_w, &l.co_b,
+                        &l.lnx_g, &l.lnx_b, &l.fc1_w, &l.fc1_b, &l.fc2_w, &l.fc2_b, &l.ln2_g, &l.ln2_b};
+        for (DevBuf* b : bs) b->release();
+    }
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+static int model_build(wm_model* m, const float* w) {
+    const wm_dims& c = m->cfg.dims;
+    const size_t d = c.d_model, f = c.ffn;
+    const int T = m->cfg.compute_dtype;
+    Reader r{w};
+    m->Cp = (c.n_mels + 31) / 32 * 32;
+    m->Vpad = (c.vocab + 15) / 16 * 16;
+    {
+        auto c1 = conv_relayout(r.take(d * c.n_mels * 3), c.d_model, c.n_mels, m->Cp);
+        WMCHK(upload(m->conv1_w, c1.data(), c1.size(), T));
+        WMCHK(upload(m->conv1_b, r.take(d), d, WM_F32));
+        auto c2 = conv_relayout(r.take(d * d * 3), c.d_model, c.d_model, c.d_model);
+        WMCHK(upload(m->conv2_w, c2.data(), c2.size(), T));
+        WMCHK(upload(m->conv2_b, r.take(d), d, WM_F32));
+        WMCHK(upload(m->enc_pos, r.take((size_t)c.n_audio_ctx * d), (size_t)c.n_audio_ctx * d, WM_F32));
+    }
+    std::vector<float> qkv(3 * d * d), qkvb(3 * d);
+    auto pack_qkv = [&](const AttnW& a) {
+        memcpy(qkv.data(), a.q_w, d * d * 4);
+        memcpy(qkv.data() + d * d, a.k_w, d * d * 4);
+        memcpy(qkv.data() + 2 * d * d, a.v_w, d * d * 4);
+        memcpy(qkvb.data(), a.q_b, d * 4);
+        memset(qkvb.data() + d, 0, d * 4);  // k_proj has no bias (layers.mojo:96-103)
+        memcpy(qkvb.data() + 2 * d, a.v_b, d * 4);
+    };
+    m->enc.resize(c.n_layers);
+    for (int i = 0; i < c.n_layers; ++i) {
+        EncLayer& l = m->enc[i];
+        AttnW a = read_attn(r, d);
+        pack_qkv(a);
+        WMCHK(upload(l.qkv_w, qkv.data(), qkv.size(), T));
+        WMCHK(upload(l.qkv_b, qkvb.data(), qkvb.size(), WM_F32));
+        WMCHK(upload(l.o_w, a.o_w, d * d, T));
+        WMCHK(upload(l.o_b, a.o_b, d, WM_F32));
+        WMCHK(upload(l.ln1_g, r.take(d), d, WM_F32));
+        WMCHK(upload(l.ln1_b, r.take(d), d, WM_F32));
+        WMCHK(upload(l.fc1_w, r.take(f * d), f * d, T));
+        WMCHK(upload(l.fc1_b, r.take(f), f, WM_F32));
+        WMCHK(upload(l.fc2_w, r.take(d * f), d * f, T));
+        WMCHK(upload(l.fc2_b, r.take(d), d, WM_F32));
+        WMCHK(upload(l.ln2_g, r.take(d), d, WM_F32));
+        WMCHK(upload(l.ln2_b, r.take(d), d, WM_F32));
+    }
+    WMCHK(upload(m->enc_ln_g, r.take(d), d, WM_F32));
+    WMCHK(upload(m->enc_ln_b, r.take(d), d, WM_F32));
+    {
+        const float* te = r.take((size_t)c.vocab * d);
+        WMCHK(upload(m->tok_emb_f, te, (size_t)c.vocab * d, WM_F32));
+        if (T != WM_F32) WMCHK(upload(m->tok_emb_t, te, (size_t)c.vocab * d, T));
+        WMCHK(upload(m->dec_pos, r.take((size_t)c.n_text_ctx * d), (size_t)c.n_text_ctx * d, WM_F32));
+    }
+    std::vector<float> ckv((size_t)c.n_layers * 2 * d * d), ckvb((size_t)c.n_layers * 2 * d, 0.f);
+    m->dec.resize(c.n_layers);
+    for (int i = 0; i < c.n_layers; ++i) {
+        DecLayer& l = m->dec[i];
+        AttnW a = read_attn(r, d);
+        pack_qkv(a);
+        WMCHK(upload(l.sqkv_w, qkv.data(), qkv.size(), T));
+        WMCHK(upload(l.sqkv_b, qkvb.data(), qkvb.size(), WM_F32));
+        WMCHK(upload(l.so_w, a.o_w, d * d, T));
+        WMCHK(upload(l.so_b, a.o_b, d, WM_F32));
+        WMCHK(upload(l.ln1_g, r.take(d), d, WM_F32));
+        WMCHK(upload(l.ln1_b, r.take(d), d, WM_F32));
+        AttnW x = read_attn(r, d);
+        WMCHK(upload(l.cq_w, x.q_w, d * d, T));
+        WMCHK(upload(l.cq_b, x.q_b, d, WM_F32));
+        memcpy(ckv.data() + (size_t)(2 * i) * d * d, x.k_w, d * d * 4);
+        memcpy(ckv.data() + (size_t)(2 * i + 1) * d * d, x.v_w, d * d * 4);
+        memcpy(ckvb.data() + (size_t)(2 * i + 1) * d, x.v_b, d * 4);
+        WMCHK(upload(l.co_w, x.o_w, d * d, T));
+        WMCHK(upload(l.co_b, x.o_b, d, WM_F32));
+        WMCHK(upload(l.lnx_g, r.take(d), d, WM_F32));
+        WMCHK(upload(l.lnx_b, r.take(d), d, WM_F32));
+        WMCHK(upload(l.fc1_w, r.take(f * d), f * d, T));
+        WMCHK(upload(l.fc1_b, r.take(f), f, WM_F32));
+        WMCHK(upload(l.fc2_w, r.take(d * f), d * f, T));
+        WMCHK(upload(l.fc2_b, r.take(d), d, WM_F32));
+        WMCHK(upload(l.ln2_g, r.take(d), d, WM_F32));
+        WMCHK(upload(l.ln2_b, r.take(d), d, WM_F32));
+    }
+    WMCHK(upload(m->dec_ln_g, r.take(d), d, WM_F32));
+    WMCHK(upload(m->dec_ln_b, r.take(d), d, WM_F32));
+    WMCHK(upload(m->cross_kv_w, ckv.data(), ckv.size(), T));
+    WMCHK(upload(m->cross_kv_b, ckvb.data(), ckvb.size(), WM_F32));
+    if (r.off != wm_synth_count(&c)) return fail(WM_E_SIZE, "internal: consumed %zu floats, expected %zu", r.off, wm_synth_count(&c));
+    return 0;
+}
+
+extern "C" int wm_model_load_memory(const float* weights, size_t n_floats, const wm_config* cfg, int device, wm_model** out) {
+    if (!weights || !cfg || !out) return fail(WM_E_ARG, "null argument");
+    WMCHK(check_cfg(cfg));
+    const size_t want = wm_synth_count(&cfg->dims);
+    if (n_floats != want)
+        return fail(WM_E_SIZE, "weight image holds %zu floats (%zu bytes), this config needs %zu (%zu bytes)", n_floats,
+                    n_floats * 4, want, want * 4);
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(WM_E_ARG, "device %d out of range (%d visible)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    wm_model* m = new wm_model();
+    m->cfg = *cfg;
+    m->device = device;
+    if (const char* e = getenv("WM_ENC_CHUNK")) m->enc_chunk = std::max(1, atoi(e));
+    hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete m;
+        return fail(WM_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    int rc = model_build(m, weights);
+    if (rc) {
+        std::string keep = g_err;
+        wm_model_free(m);
+        g_err = keep;
+        return rc;
+    }
+    *out = m;
+    return 0;
+}
+
+extern "C" int wm_model_load(const char* path, const wm_config* cfg, int device, wm_model** out) {
+    if (!path || !cfg || !out) return fail(WM_E_ARG, "null argument");
+    WMCHK(check_cfg(cfg));
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(WM_E_IO, "cannot open %s", path);
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    const size_t want = wm_synth_count(&cfg->dims) * 4;
+    if (sz < 0 || (size_t)sz != want) {
+        fclose(f);
+        return fail(WM_E_SIZE, "%s is %ld bytes, this config needs %zu", path, sz, want);
+    }
+    std::vector<float> buf(want / 4);
+    size_t got = fread(buf.data(), 1, want, f);
+    fclose(f);
+    if (got != want) return fail(WM_E_IO, "short read on %s", path);
+    return wm_model_load_memory(buf.data(), buf.size(), cfg, device, out);
+}
+
+// ---- state ---------------------------------------------------------------------------------------------------
+extern "C" void wm_state_free(wm_state* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->m->device);
+    DevBuf* bs[] = {&s->mel_dev, &s->mel_t, &s->h1, &s->x, &s->xn, &s->qkv, &s->ao, &s->hid, &s->enc_t, &s->enc_f,
+                    &s->cross_kv, &s->self_kv, &s->dx, &s->dq, &s->dattn, &s->dhid, &s->part_o, &s->part_ml, &s->logits,
+                    &s->tok, &s->pos, &s->ctl, &s->out_tokens, &s->n_tokens, &s->finished};
+    for (DevBuf* b : bs) b->release();
+    delete s;
+}
+
+static const int OUT_STRIDE_MAX = 1024;
+
+extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
+    if (!m || !out || B <= 0) return fail(WM_E_ARG, "bad argument");
+    if (B > m->cfg.max_batch) return fail(WM_E_ARG, "batch %d exceeds max_batch %d", B, m->cfg.max_batch);
+    HIPCHK(hipSetDevice(m->device));
+    const wm_dims& c = m->cfg.dims;
+    const size_t d = c.d_model, L = 2 * (size_t)c.n_audio_ctx, T = c.n_audio_ctx;
+    const size_t ts = dt_size(m->cfg.compute_dtype), ks = dt_size(m->cfg.kv_dtype);
+    wm_state* s = new wm_state();
+    s->m = m;
+    s->B = B;
+    s->Bc = std::min(B, m->enc_chunk);
+    s->nsplit = std::min(32, std::max((int)((T + 511) / 512), (1024 + B - 1) / B));
+    s->out_stride = OUT_STRIDE_MAX;
+    const size_t Bc = s->Bc;
+    const size_t Mp = (Bc * T + 127) / 128 * 128 + 128;  // padded rows: tail tiles read (never store) past M
+    int rc = 0;
+    auto A = [&](DevBuf& b, size_t bytes, bool zero = false) {
+        if (!rc) rc = b.alloc(bytes, zero);
+    };
+    A(s->mel_dev, (size_t)B * c.n_mels * L * 4);
+    A(s->mel_t, (Bc * (L + 2) + 256) * m->Cp * ts, true);
+    A(s->h1, (Bc * (L + 2) + 256) * d * ts, true);  // rows 0 and L+1 of each utterance stay zero = conv padding
+    A(s->x, Mp * d * 4, true);
+    A(s->xn, Mp * d * ts, true);
+    A(s->qkv, Mp * 3 * d * ts, true);
+    A(s->ao, Mp * d * ts, true);
+    A(s->hid, Mp * c.ffn * ts, true);
+    A(s->enc_t, Mp * d * ts, true);
+    A(s->enc_f, (size_t)B * T * d * 4);
+    A(s->cross_kv, (size_t)c.n_layers * 2 * B * T * d * ks);
+    A(s->self_kv, (size_t)c.n_layers * 2 * B * c.n_text_ctx * d * ks, true);
+    A(s->dx, (size_t)B * d * 4);
+    A(s->dq, (size_t)B * d * 4);
+    A(s->dattn, (size_t)B * d * 4);
+    A(s->dhid, (size_t)B * c.ffn * 4);
+    A(s->part_o, (size_t)B * s->nsplit * d * 4);
+    A(s->part_ml, (size_t)B * s->nsplit * c.n_heads * 2 * 4);
+    A(s->logits, (size_t)B * m->Vpad * 4);
+    A(s->tok, (size_t)B * 4, true);
+    A(s->pos, (size_t)B * 4, true);
+    A(s->ctl, sizeof(StepCtl), true);
+    A(s->out_tokens, (size_t)B * s->out_stride * 4, true);
+    A(s->n_tokens, (size_t)B * 4, true);
+    A(s->finished, (size_t)B * 4, true);
+    if (rc) {
+        std::string keep = g_err;
+        wm_state_free(s);
+        g_err = keep;
+        return rc;
+    }
+    *out = s;
+    return 0;
+}
+
+extern "C" int wm_state_reset(wm_state* s) {
+    if (!s) return fail(WM_E_ARG, "null state");
+    HIPCHK(hipSetDevice(s->m->device));
+    hipStream_t st = s->m->stream;
+    HIPCHK(hipMemsetAsync(s->ctl.p, 0, sizeof(StepCtl), st));
+    HIPCHK(hipMemsetAsync(s->n_tokens.p, 0, s->n_tokens.bytes, st));
+    HIPCHK(hipMemsetAsync(s->finished.p, 0, s->finished.bytes, st));
+    s->has_enc = s->has_cross = false;
+    s->host_len = 0;
+    return 0;
+}
+extern "C" int wm_state_len(const wm_state* s) { return s ? s->host_len : -1; }
+
+// ---- encoder: whisper.mojo:71-99 ------------------------------------------------------------------------------------
+static void* off_bytes(const DevBuf& b, size_t bytes) { return (char*)b.p + bytes; }
+
+static int cross_kv_chunk(wm_model* m, wm_state* s, int c0, int bc) {
+    // cross K/V for utterances [c0, c0+bc) from enc_t (rows 0..bc*T): layers.mojo:150-154, all layers in one GEMM
+    const wm_dims& c = m->cfg.dims;
+    const size_t d = c.d_model, T = c.n_audio_ctx;
+    GemmParams p{};
+    p.A = s->enc_t.p;
+    p.W = m->cross_kv_w.p;
+    p.C = off_bytes(s->cross_kv, (size_t)c0 * T * d * dt_size(m->cfg.kv_dtype));
+    p.M = (int)(bc * T);
+    p.N = c.n_layers * 2 * c.d_model;
+    p.K = c.d_model;
+    p.lda = d;
+    p.ldw = d;
+    p.ldc = d;
+    p.bias = m->cross_kv_b.as<float>();
+    p.group_n = c.d_model;
+    p.group_stride = (long)((size_t)s->B * T * d);
+    gemm_dispatch(m->cfg.compute_dtype, m->cfg.kv_dtype, p, 1, m->stream);
+    return 0;
+}
+
+static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B) {
+    const wm_dims& c = m->cfg.dims;
+    const int T = m->cfg.compute_dtype;
+    const size_t d = c.d_model, L = 2 * (size_t)c.n_audio_ctx, NT = c.n_audio_ctx, ts = dt_size(T);
+    hipStream_t st = m->stream;
+    const float scale = 1.0f / sqrtf(64.0f);
+    for (int c0 = 0; c0 < B; c0 += s->Bc) {
+        const int bc = std::min(s->Bc, B - c0);
+        const int M = (int)(bc * NT);
+        DISPATCH_DT(T, TT, launch_mel_transpose_pad<TT>(mel_dev + (size_t)c0 * c.n_mels * L, s->mel_t.p, bc, c.n_mels, (int)L, m->Cp, st));
+        {  // conv1 + GELU -> h1 rows 1..L (token-major)   whisper.mojo:73-75
+            GemmParams p{};
+            p.A = s->mel_t.p;
+            p.W = m->conv1_w.p;
+            p.C = off_bytes(s->h1, d * ts);
+            p.M = (int)L;
+            p.N = c.d_model;
+            p.K = 3 * m->Cp;
+            p.lda = m->Cp;
+            p.ldw = 3 * m->Cp;
+            p.ldc = d;
+            p.strideA = (long)((L + 2) * m->Cp);
+            p.strideC = (long)((L + 2) * d);
+            p.bias = m->conv1_b.as<float>();
+            p.act = 1;
+            p.gelu_mode = m->cfg.gelu_mode;
+            gemm_dispatch(T, T, p, bc, st);
+        }
+        {  // conv2 (stride 2) + GELU + pos_emb -> x   whisper.mojo:78-89
+            GemmParams p{};
+            p.A = s->h1.p;
+            p.W = m->conv2_w.p;
+            p.C = s->x.p;
+            p.M = (int)NT;
+            p.N = c.d_model;
+            p.K = 3 * c.d_model;
+            p.lda = 2 * d;
+            p.ldw = 3 * d;
+            p.ldc = d;
+            p.strideA = (long)((L + 2) * d);
+            p.strideC = (long)(NT * d);
+            p.bias = m->conv2_b.as<float>();
+            p.act = 1;
+            p.gelu_mode = m->cfg.gelu_mode;
+            p.pos = m->enc_pos.as<float>();
+            gemm_dispatch(T, WM_F32, p, bc, st);
+        }
+        for (int l = 0; l < c.n_layers; ++l) {  // layers.mojo:435-519 with is_decoder=False
+            EncLayer& w = m->enc[l];
+            DISPATCH_DT(T, TT, launch_layernorm_rows<TT>(s->x.as<float>(), w.ln1_g.as<float>(), w.ln1_b.as<float>(), s->xn.p, nullptr, M, c.d_model, 1e-5f, st));
+            GemmParams p{};
+            p.A = s->xn.p;
+            p.W = w.qkv_w.p;
+            p.C = s->qkv.p;
+            p.M = M;
+            p.N = 3 * c.d_model;
+            p.K = c.d_model;
+            p.lda = d;
+            p.ldw = d;
+            p.ldc = 3 * d;
+            p.bias = w.qkv_b.as<float>();
+            gemm_dispatch(T, T, p, 1, st);
+            DISPATCH_DT(T, TT, launch_flash_attn_enc<TT>(s->qkv.p, s->ao.p, bc, c.n_heads, c.n_audio_ctx, scale, st));
+            GemmParams o{};
+            o.A = s->ao.p;
+            o.W = w.o_w.p;
+            o.C = s->x.p;
+            o.M = M;
+            o.N = c.d_model;
+            o.K = c.d_model;
+            o.lda = d;
+            o.ldw = d;
+            o.ldc = d;
+            o.bias = w.o_b.as<float>();
+            o.residual = s->x.as<float>();
+            o.ldr = d;
+            gemm_dispatch(T, WM_F32, o, 1, st);
+            DISPATCH_DT(T, TT, launch_layernorm_rows<TT>(s->x.as<float>(), w.ln2_g.as<float>(), w.ln2_b.as<float>(), s->xn.p, nullptr, M, c.d_model, 1e-5f, st));
+            GemmParams f1{};
+            f1.A = s->xn.p;
+            f1.W = w.fc1_w.p;
+            f1.C = s->hid.p;
+            f1.M = M;
+            f1.N = c.ffn;
+            f1.K = c.d_model;
+            f1.lda = d;
+            f1.ldw = d;
+            f1.ldc = c.ffn;
+            f1.bias = w.fc1_b.as<float>();
+            f1.act = 1;
+            f1.gelu_mode = m->cfg.gelu_mode;
+            gemm_dispatch(T, T, f1, 1, st);
+            GemmParams f2{};
+            f2.A = s->hid.p;
+            f2.W = w.fc2_w.p;
+            f2.C = s->x.p;
+            f2.M = M;
+            f2.N = c.d_model;
+            f2.K = c.ffn;
+            f2.lda = c.ffn;
+            f2.ldw = c.ffn;
+            f2.ldc = d;
+            f2.bias = w.fc2_b.as<float>();
+            f2.residual = s->x.as<float>();
+            f2.ldr = d;
+            gemm_dispatch(T, WM_F32, f2, 1, st);
+        }
+        float* encf = s->enc_f.as<float>() + (size_t)c0 * NT * d;
+        DISPATCH_DT(T, TT, launch_layernorm_rows<TT>(s->x.as<float>(), m->enc_ln_g.as<float>(), m->enc_ln_b.as<float>(), s->enc_t.p, encf, M, c.d_model, 1e-5f, st));
+        WMCHK(cross_kv_chunk(m, s, c0, bc));
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int check_state(wm_model* m, wm_state* s, int B) {
+    if (!m || !s) return fail(WM_E_ARG, "null handle");
+    if (s->m != m) return fail(WM_E_ARG, "state belongs to another model");
+    if (B != s->B) return fail(WM_E_ARG, "B=%d but the state was created for %d", B, s->B);
+    return 0;
+}
+
+extern "C" int wm_encode(wm_model* m, wm_state* s, const float* mel, int mel_on_device, int B, float* enc_out) {
+    WMCHK(check_state(m, s, B));
+    if (!mel) return fail(WM_E_ARG, "null mel");
+    HIPCHK(hipSetDevice(m->device));
+    WMCHK(wm_state_reset(s));
+    const wm_dims& c = m->cfg.dims;
+    const float* mel_dev = mel;
+    if (!mel_on_device) {
+        HIPCHK(hipMemcpyAsync(s->mel_dev.p, mel, (size_t)B * c.n_mels * 2 * c.n_audio_ctx * 4, hipMemcpyHostToDevice, m->stream));
+        mel_dev = s->mel_dev.as<float>();
+    }
+    WMCHK(run_encoder(m, s, mel_dev, B));
+    s->has_enc = s->has_cross = true;
+    if (enc_out) HIPCHK(hipMemcpyAsync(enc_out, s->enc_f.p, (size_t)B * c.n_audio_ctx * c.d_model * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+extern "C" int wm_state_set_encoder_output(wm_model* m, wm_state* s, const float* enc_out, int B) {
+    WMCHK(check_state(m, s, B));
+    if (!enc_out) return fail(WM_E_ARG, "null enc_out");
+    HIPCHK(hipSetDevice(m->device));
+    WMCHK(wm_state_reset(s));
+    const wm_dims& c = m->cfg.dims;
+    const size_t NT = c.n_audio_ctx, d = c.d_model;
+    HIPCHK(hipMemcpyAsync(s->enc_f.p, enc_out, (size_t)B * NT * d * 4, hipMemcpyHostToDevice, m->stream));
+    for (int c0 = 0; c0 < B; c0 += s->Bc) {
+        const int bc = std::min(s->Bc, B - c0);
+        DISPATCH_DT(m->cfg.compute_dtype, TT, launch_convert<TT>(s->enc_f.as<float>() + (size_t)c0 * NT * d, s->enc_t.p, (size_t)bc * NT * d, m->stream));
+        WMCHK(cross_kv_chunk(m, s, c0, bc));
+    }
+    HIPCHK(hipStreamSynchronize(m->stream));
+    s->has_enc = s->has_cross = true;
+    return 0;
+}
+
+// ---- one decode step for all B utterances: whisper.mojo:130-167 with L_tgt = 1 ------------------------------------
+static void dec_linear_dispatch(int dt, const DecLinearParams& p, hipStream_t st) {
+    DISPATCH_DT(dt, TT, launch_dec_linear<TT>(p, st));
+}
+static void attn_decode_dispatch(int dt, const AttnDecParams& p, hipStream_t st) {
+    DISPATCH_DT(dt, TT, launch_attn_decode<TT>(p, st));
+}
+
+static void launch_cross_attn(wm_model* m, wm_state* s, int l) {
+    const wm_dims& c = m->cfg.dims;
+    const size_t d = c.d_model, ks = dt_size(m->cfg.kv_dtype);
+    const size_t cross_l = (size_t)s->B * c.n_audio_ctx * d;
+    AttnDecParams a{};
+    a.q = s->dq.as<float>();
+    a.K = off_bytes(s->cross_kv, (size_t)(2 * l) * cross_l * ks);
+    a.V = off_bytes(s->cross_kv, (size_t)(2 * l + 1) * cross_l * ks);
+    a.batch_stride = (long)((size_t)c.n_audio_ctx * d);
+    a.n_keys = c.n_audio_ctx;
+    a.ctl = s->ctl.as<StepCtl>();
+    a.nsplit = s->nsplit;
+    a.scale = 1.0f / sqrtf(64.0f);
+    a.part_o = s->part_o.as<float>();
+    a.part_ml = s->part_ml.as<float>();
+    a.H = c.n_heads;
+    a.d = c.d_model;
+    a.B = s->B;
+    attn_decode_dispatch(m->cfg.kv_dtype, a, m->stream);
+}
+
+static void decode_core(wm_model* m, wm_state* s, bool want_logits) {
+    const wm_dims& c = m->cfg.dims;
+    const int T = m->cfg.compute_dtype, KV = m->cfg.kv_dtype;
+    const int B = s->B;
+    const size_t d = c.d_model, ks = dt_size(KV);
+    hipStream_t st = m->stream;
+    const StepCtl* ctl = s->ctl.as<StepCtl>();
+    const float scale = 1.0f / sqrtf(64.0f);
+    const size_t self_l = (size_t)B * c.n_text_ctx * d;  // elements per (layer, K|V)
+    launch_dec_embed(m->tok_emb_f.as<float>(), m->dec_pos.as<float>(), s->tok.as<int>(), s->pos.as<int>(), s->dx.as<float>(), B, c.d_model, st);
+    for (int l = 0; l < c.n_layers; ++l) {
+        DecLayer& w = m->dec[l];
+        void* sk = off_bytes(s->self_kv, (size_t)(2 * l) * self_l * ks);
+        void* sv = off_bytes(s->self_kv, (size_t)(2 * l + 1) * self_l * ks);
+        {  // LN1 -> q | k,v appended to the cache at row current_len   (layers.mojo:118-147)
+            DecLinearParams p{};
+            p.x = s->dx.as<float>();
+            p.ldx = c.d_model;
+            p.ln_g = w.ln1_g.as<float>();
+            p.ln_b = w.ln1_b.as<float>();
+            p.W = w.sqkv_w.p;
+            p.N = 3 * c.d_model;
+            p.K = c.d_model;
+            p.B = B;
+            p.bias = w.sqkv_b.as<float>();
+            p.out = s->dq.as<float>();
+            p.ldo = c.d_model;
+            p.kcache = sk;
+            p.vcache = sv;
+            p.kv_batch_stride = (long)((size_t)c.n_text_ctx * d);
+            p.d_model = c.d_model;
+            p.kv_dtype = KV;
+            p.ctl = ctl;
+            dec_linear_dispatch(T, p, st);
+        }
+        {  // self-attention over current_len+1 cached rows   (layers.mojo:186-272)
+            AttnDecParams a{};
+            a.q = s->dq.as<float>();
+            a.K = sk;
+            a.V = sv;
+            a.batch_stride = (long)((size_t)c.n_text_ctx * d);
+            a.n_keys = -1;
+            a.ctl = ctl;
+            a.nsplit = 1;
+            a.scale = scale;
+            a.direct_out = s->dattn.as<float>();
+            a.H = c.n_heads;
+            a.d = c.d_model;
+            a.B = B;
+            attn_decode_dispatch(KV, a, st);
+        }
+        auto proj_residual = [&](const float* in, int K, const DevBuf& W, const DevBuf& bias) {  // x += in·Wᵀ + b
+            DecLinearParams p{};
+            p.x = in;
+            p.ldx = K;
+            p.W = W.p;
+            p.N = c.d_model;
+            p.K = K;
+            p.B = B;
+            p.bias = bias.as<float>();
+            p.residual = s->dx.as<float>();
+            p.ldr = c.d_model;
+            p.out = s->dx.as<float>();
+            p.ldo = c.d_model;
+            dec_linear_dispatch(T, p, st);
+        };
+        proj_residual(s->dattn.as<float>(), c.d_model, w.so_w, w.so_b);
+        {  // LNx -> cross q
+            DecLinearParams p{};
+            p.x = s->dx.as<float>();
+            p.ldx = c.d_model;
+            p.ln_g = w.lnx_g.as<float>();
+            p.ln_b = w.lnx_b.as<float>();
+            p.W = w.cq_w.p;
+            p.N = c.d_model;
+            p.K = c.d_model;
+            p.B = B;
+            p.bias = w.cq_b.as<float>();
+            p.out = s->dq.as<float>();
+            p.ldo = c.d_model;
+            dec_linear_dispatch(T, p, st);
+        }
+        launch_cross_attn(m, s, l);
+        launch_attn_combine(s->part_o.as<float>(), s->part_ml.as<float>(), s->dattn.as<float>(), B, s->nsplit, c.n_heads, c.d_model, st);
+        proj_residual(s->dattn.as<float>(), c.d_model, w.co_w, w.co_b);
+        {  // LN2 -> fc1 + GELU
+            DecLinearParams p{};
+            p.x = s->dx.as<float>();
+            p.ldx = c.d_model;
+            p.ln_g = w.ln2_g.as<float>();
+            p.ln_b = w.ln2_b.as<float>();
+            p.W = w.fc1_w.p;
+            p.N = c.ffn;
+            p.K = c.d_model;
+            p.B = B;
+            p.bias = w.fc1_b.as<float>();
+            p.act = 1;
+            p.gelu_mode = m->cfg.gelu_mode;
+            p.out = s->dhid.as<float>();
+            p.ldo = c.ffn;
+            dec_linear_dispatch(T, p, st);
+        }
+        proj_residual(s->dhid.as<float>(), c.ffn, w.fc2_w, w.fc2_b);
+    }
+    if (want_logits) {  // final LN + tied-embedding logits (whisper.mojo:156-166), no bias
+        DecLinearParams p{};
+        p.x = s->dx.as<float>();
+        p.ldx = c.d_model;
+        p.ln_g = m->dec_ln_g.as<float>();
+        p.ln_b = m->dec_ln_b.as<float>();
+        p.W = T == WM_F32 ? m->tok_emb_f.p : m->tok_emb_t.p;
+        p.N = c.vocab;
+        p.K = c.d_model;
+        p.B = B;
+        p.out = s->logits.as<float>();
+        p.ldo = m->Vpad;
+        dec_linear_dispatch(T, p, st);
+    }
+}
+
+static ArgmaxParams argmax_params(wm_model* m, wm_state* s, bool record, int eot, int ignore_eot) {
+    ArgmaxParams a{};
+    a.logits = s->logits.as<float>();
+    a.ldl = m->Vpad;
+    a.V = m->cfg.dims.vocab;
+    a.B = s->B;
+    a.next = s->tok.as<int>();
+    a.out_tokens = record ? s->out_tokens.as<int>() : nullptr;
+    a.out_stride = s->out_stride;
+    a.n_tokens = s->n_tokens.as<int>();
+    a.finished = s->finished.as<int>();
+    a.ctl = s->ctl.as<StepCtl>();
+    a.eot = eot;
+    a.ignore_eot = ignore_eot;
+    return a;
+}
+
+extern "C" int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, int q_len, const int32_t* start_pos,
+                              float* logits, int32_t* next) {
+    if (!m || !s || !tokens || !start_pos || q_len <= 0) return fail(WM_E_ARG, "bad argument");
+    WMCHK(check_state(m, s, s->B));
+    if (!s->has_enc) return fail(WM_E_STATE, "no encoder output in this state (call wm_encode first)");
+    const wm_dims& c = m->cfg.dims;
+    const int B = s->B;
+    if (s->host_len + q_len > c.n_text_ctx) return fail(WM_E_STATE, "KV cache full (%d + %d > %d)", s->host_len, q_len, c.n_text_ctx);
+    for (int b = 0; b < B; ++b) {
+        if (start_pos[b] < 0 || start_pos[b] + q_len > c.n_text_ctx) return fail(WM_E_ARG, "start_pos[%d]=%d out of range", b, start_pos[b]);
+        for (int i = 0; i < q_len; ++i)
+            if (tokens[b * q_len + i] < 0 || tokens[b * q_len + i] >= c.vocab) return fail(WM_E_ARG, "token id out of range");
+    }
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    std::vector<int32_t> col(B), pos(B);
+    for (int i = 0; i < q_len; ++i) {
+        for (int b = 0; b < B; ++b) {
+            col[b] = tokens[b * q_len + i];
+            pos[b] = start_pos[b] + i;
+        }
+        HIPCHK(hipMemcpyAsync(s->tok.p, col.data(), B * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->pos.p, pos.data(), B * 4, hipMemcpyHostToDevice, st));
+        launch_set_step(s->ctl.as<StepCtl>(), s->host_len, 1, nullptr, 0, nullptr, 0, B, st);
+        decode_core(m, s, i == q_len - 1);
+        HIPCHK(hipStreamSynchronize(st));  // col/pos are reused next iteration
+        s->host_len += 1;
+    }
+    launch_set_step(s->ctl.as<StepCtl>(), s->host_len, 1, nullptr, 0, nullptr, 0, B, st);
+    if (next) {
+        launch_argmax_step(argmax_params(m, s, false, -1, 1), st);
+        HIPCHK(hipMemcpyAsync(next, s->tok.p, B * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (logits)
+        HIPCHK(hipMemcpy2DAsync(logits, (size_t)c.vocab * 4, s->logits.p, (size_t)m->Vpad * 4, (size_t)c.vocab * 4, B, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- Whisper.transcribe: whisper.mojo:184-223 ------------------------------------------------------------------------
+static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o) {
+    const int B = s->B;
+    hipStream_t st = m->stream;
+    StepCtl* ctl = s->ctl.as<StepCtl>();
+    // tokens = prompt (whisper.mojo:187-191, 200-202)
+    std::vector<int32_t> rows((size_t)B * s->out_stride, 0), nt(B, o->n_prompt);
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < o->n_prompt; ++i) rows[(size_t)b * s->out_stride + i] = o->prompt[i];
+    HIPCHK(hipMemcpyAsync(s->out_tokens.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->n_tokens.p, nt.data(), B * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(s->finished.p, 0, B * 4, st));
+    HIPCHK(hipMemsetAsync(s->ctl.p, 0, sizeof(StepCtl), st));
+    HIPCHK(hipStreamSynchronize(st));  // rows / nt are pageable host memory
+    // prefill (whisper.mojo:195, start_pos=0): the q_len = n_prompt causal block equals n_prompt single-token steps
+    for (int i = 0; i < o->n_prompt; ++i) {
+        launch_set_step(ctl, i, 1, s->pos.as<int>(), i, s->tok.as<int>(), o->prompt[i], B, st);
+        decode_core(m, s, i == o->n_prompt - 1);
+    }
+    launch_argmax_step(argmax_params(m, s, true, o->eot, o->ignore_eot), st);  // :198-203
+    // incremental steps: start_pos = current_len - 1 (reference, :217) or current_len (HF)
+    const int first_pos = o->pos_mode == WM_POS_REF ? o->n_prompt - 1 : o->n_prompt;
+    launch_set_step(ctl, o->n_prompt, 1, s->pos.as<int>(), first_pos, nullptr, 0, B, st);
+    StepCtl* h_ctl = nullptr;
+    HIPCHK(hipHostMalloc((void**)&h_ctl, sizeof(StepCtl), 0));
+    int rc = 0;
+    for (int it = 0; it < o->max_loop; ++it) {
+        if (!o->ignore_eot && (it % 8) == 0) {  // "if next_token == eot: break" for the whole batch
+            hipError_t e = hipMemcpyAsync(h_ctl, ctl, sizeof(StepCtl), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) {
+                rc = fail(WM_E_HIP, "poll: %s", hipGetErrorString(e));
+                break;
+            }
+            if (h_ctl->n_finished >= B) break;
+        }
+        decode_core(m, s, true);
+        launch_argmax_step(argmax_params(m, s, true, o->eot, o->ignore_eot), st);
+        launch_advance(ctl, s->pos.as<int>(), B, st);
+    }
+    (void)hipHostFree(h_ctl);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wm_transcribe(wm_model* m, const float* mel, int mel_on_device, int B, const wm_decode_opts* o,
+                             int32_t* tokens_out, int32_t* n_tokens) {
+    if (!m || !mel || !o || !tokens_out || !n_tokens || B <= 0) return fail(WM_E_ARG, "bad argument");
+    if (!o->prompt || o->n_prompt <= 0 || o->max_loop < 0) return fail(WM_E_ARG, "bad decode options");
+    const wm_dims& c = m->cfg.dims;
+    const int total = o->n_prompt + 1 + o->max_loop;
+    if (total > c.n_text_ctx + 1 || total > OUT_STRIDE_MAX)
+        return fail(WM_E_ARG, "n_prompt + 1 + max_loop = %d exceeds the decoder context %d", total, c.n_text_ctx);
+    for (int i = 0; i < o->n_prompt; ++i)
+        if (o->prompt[i] < 0 || o->prompt[i] >= c.vocab) return fail(WM_E_ARG, "prompt id out of range");
+    HIPCHK(hipSetDevice(m->device));
+    if (!m->cached || m->cached->B != B) {
+        if (m->cached) wm_state_free(m->cached);
+        m->cached = nullptr;
+        WMCHK(wm_state_new(m, B, &m->cached));
+    }
+    wm_state* s = m->cached;
+    WMCHK(wm_state_reset(s));
+    const float* mel_dev = mel;
+    if (!mel_on_device) {
+        HIPCHK(hipMemcpyAsync(s->mel_dev.p, mel, (size_t)B * c.n_mels * 2 * c.n_audio_ctx * 4, hipMemcpyHostToDevice, m->stream));
+        mel_dev = s->mel_dev.as<float>();
+    }
+    WMCHK(run_encoder(m, s, mel_dev, B));
+    s->has_enc = s->has_cross = true;
+    WMCHK(transcribe_decode(m, s, o));
+    HIPCHK(hipMemcpy2DAsync(tokens_out, (size_t)total * 4, s->out_tokens.p, (size_t)s->out_stride * 4, (size_t)total * 4, B, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(n_tokens, s->n_tokens.p, B * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+// ---- measurement helpers ------------------------------------------------------------------------------------------------
+extern "C" int wm_bench_bytes(wm_model* m, wm_state* s, int which, double* bytes) {
+    if (!m || !s || !bytes) return fail(WM_E_ARG, "null argument");
+    const wm_dims& c = m->cfg.dims;
+    const double d = c.d_model, H = c.n_heads, B = s->B;
+    const double ks = dt_size(m->cfg.kv_dtype), ws = dt_size(m->cfg.compute_dtype);
+    if (which == WM_KERNEL_CROSS_ATTN) {
+        // one layer: K and V rows of every utterance once + q in + partials out
+        *bytes = B * 2.0 * c.n_audio_ctx * d * ks + B * d * 4 + B * s->nsplit * (d + 2 * H) * 4;
+    } else if (which == WM_KERNEL_DECODE_STEP) {
+        // every weight once per step, KV once per utterance, KV write, logits materialised
+        const double f = c.ffn, L = c.n_layers, V = c.vocab;
+        const double p_blk = 8 * d * d + 2 * f * d + (4 + 4 + 1 + 1 + 6) * d + f;  // 2 attn (4 mats each) + mlp + biases + 3 LN
+        const double t = s->host_len > 0 ? s->host_len : 50;
+        *bytes = ws * (L * (8 * d * d + 2 * f * d) + V * d) + 4 * (L * (p_blk - 8 * d * d - 2 * f * d) + 2 * d) +
+                 B * L * 2 * d * ks * (c.n_audio_ctx + t) + B * L * 2 * d * ks + B * V * 4.0 * 2 + B * 4;
+    } else if (which == WM_KERNEL_ENCODER) {
+        *bytes = 0;  // MFMA-bound: see wm_bench_flops in DESIGN.md
+    } else {
+        return fail(WM_E_ARG, "unknown kernel id %d", which);
+    }
+    return 0;
+}
+
+extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, float* avg_us) {
+    if (!m || !s || !avg_us || reps <= 0) return fail(WM_E_ARG, "bad argument");
+    if (!s->has_cross) return fail(WM_E_STATE, "state has no cross K/V (call wm_encode first)");
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    const int L = m->cfg.dims.n_layers;
+    if (which == WM_KERNEL_CROSS_ATTN) {
+        for (int i = 0; i < L; ++i) launch_cross_attn(m, s, i);  // warm-up
+        HIPCHK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) launch_cross_attn(m, s, i % L);  // cycles the layers: 4 x 295 MB > 256 MB L3
+        HIPCHK(hipEventRecord(e1, st));
+    } else if (which == WM_KERNEL_DECODE_STEP) {
+        const int len0 = std::max(s->host_len, 1);
+        launch_set_step(s->ctl.as<StepCtl>(), len0, 1, nullptr, 0, nullptr, 0, s->B, st);
+        decode_core(m, s, true);
+        HIPCHK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) decode_core(m, s, true);
+        HIPCHK(hipEventRecord(e1, st));
+    } else if (which == WM_KERNEL_ENCODER) {
+        WMCHK(run_encoder(m, s, s->mel_dev.as<float>(), s->B));
+        HIPCHK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) WMCHK(run_encoder(m, s, s->mel_dev.as<float>(), s->B));
+        HIPCHK(hipEventRecord(e1, st));
+    } else {
+        return fail(WM_E_ARG, "unknown kernel id %d", which);
+    }
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_us = ms * 1000.0f / (float)reps;
+    return 0;
+}
+
+// ---- op-level entry points (whisper_tensor.mojo) --------------------------------------------------------------------------
+struct TmpDev {
+    std::vector<DevBuf> bufs;
+    ~TmpDev() {
+        for (auto& b : bufs) b.release();
+    }
+    DevBuf& add() {
+        bufs.emplace_back();
+        return bufs.back();
+    }
+};
+
+extern "C" int wm_op_matmul_nt(float* C, const float* A, const float* Bm, const float* bias, int M, int N, int K, int dtype) {
+    if (!C || !A || !Bm || M <= 0 || N <= 0 || K <= 0) return fail(WM_E_ARG, "bad argument");
+    if (K % 32) return fail(WM_E_ARG, "K must be a multiple of 32");
+    if (dtype < 0 || dtype > 2) return fail(WM_E_ARG, "bad dtype");
+    TmpDev t;
+    t.bufs.reserve(8);
+    hipStream_t st = nullptr;
+    if (N % 128 == 0) {  // dense path: the encoder GEMM kernel
+        const size_t Mp = ((size_t)M + 127) / 128 * 128;
+        std::vector<float> Ap(Mp * K, 0.f);
+        memcpy(Ap.data(), A, (size_t)M * K * 4);
+        DevBuf &a = t.add(), &w = t.add(), &c = t.add(), &b = t.add();
+        WMCHK(upload(a, Ap.data(), Ap.size(), dtype));
+        WMCHK(upload(w, Bm, (size_t)N * K, dtype));
+        WMCHK(c.alloc((size_t)M * N * 4));
+        if (bias) WMCHK(upload(b, bias, N, WM_F32));
+        GemmParams p{};
+        p.A = a.p;
+        p.W = w.p;
+        p.C = c.p;
+        p.M = M;
+        p.N = N;
+        p.K = K;
+        p.lda = K;
+        p.ldw = K;
+        p.ldc = N;
+        p.bias = bias ? b.as<float>() : nullptr;
+        gemm_dispatch(dtype, WM_F32, p, 1, st);
+        HIPCHK(hipMemcpy(C, c.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    } else {  // skinny path: the decode-step linear kernel
+        const int Np = (N + 15) / 16 * 16;
+        DevBuf &a = t.add(), &w = t.add(), &c = t.add(), &b = t.add();
+        WMCHK(upload(a, A, (size_t)M * K, WM_F32));
+        WMCHK(upload(w, Bm, (size_t)N * K, dtype));
+        WMCHK(c.alloc((size_t)M * Np * 4));
+        if (bias) WMCHK(upload(b, bias, N, WM_F32));
+        DecLinearParams p{};
+        p.x = a.as<float>();
+        p.ldx = K;
+        p.W = w.p;
+        p.N = N;
+        p.K = K;
+        p.B = M;
+        p.bias = bias ? b.as<float>() : nullptr;
+        p.out = c.as<float>();
+        p.ldo = Np;
+        dec_linear_dispatch(dtype, p, st);
+        HIPCHK(hipMemcpy2D(C, (size_t)N * 4, c.p, (size_t)Np * 4, (size_t)N * 4, M, hipMemcpyDeviceToHost));
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wm_op_layer_norm(float* out, const float* inp, const float* gamma, const float* beta, int rows, int cols, float eps) {
+    if (!out || !inp || !gamma || !beta || rows <= 0 || cols <= 0) return fail(WM_E_ARG, "bad argument");
+    if (cols % 64 || cols > 1024) return fail(WM_E_ARG, "cols must be a multiple of 64 and <= 1024");
+    TmpDev t;
+    t.bufs.reserve(8);
+    DevBuf &x = t.add(), &g = t.add(), &b = t.add(), &o = t.add();
+    WMCHK(upload(x, inp, (size_t)rows * cols, WM_F32));
+    WMCHK(upload(g, gamma, cols, WM_F32));
+    WMCHK(upload(b, beta, cols, WM_F32));
+    WMCHK(o.alloc((size_t)rows * cols * 4));
+    launch_layernorm_rows<float>(x.as<float>(), g.as<float>(), b.as<float>(), nullptr, o.as<float>(), rows, cols, eps, nullptr);
+    HIPCHK(hipMemcpy(out, o.p, (size_t)rows * cols * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int wm_op_gelu(float* tt, size_t n, int mode) {
+    if (!tt || (mode != 0 && mode != 1)) return fail(WM_E_ARG, "bad argument");
+    if (n == 0) return 0;
+    TmpDev t;
+    t.bufs.reserve(2);
+    DevBuf& x = t.add();
+    WMCHK(upload(x, tt, n, WM_F32));
+    launch_gelu(x.as<float>(), n, mode, nullptr);
+    HIPCHK(hipMemcpy(tt, x.p, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int wm_op_softmax_rows(float* tt, int rows, int cols) {
+    if (!tt || rows <= 0 || cols <= 0) return fail(WM_E_ARG, "bad argument");
+    TmpDev t;
+    t.bufs.reserve(2);
+    DevBuf& x = t.add();
+    WMCHK(upload(x, tt, (size_t)rows * cols, WM_F32));
+    launch_softmax_rows(x.as<float>(), rows, cols, nullptr);
+    HIPCHK(hipMemcpy(tt, x.p, (size_t)rows * cols * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int wm_op_argmax(const float* tt, int n, int32_t* idx) {
+    if (!tt || !idx || n <= 0) return fail(WM_E_ARG, "bad argument");
+    TmpDev t;
+    t.bufs.reserve(2);
+    DevBuf &x = t.add(), &o = t.add();
+    WMCHK(upload(x, tt, n, WM_F32));
+    WMCHK(o.alloc(4));
+    launch_argmax_plain(x.as<float>(), n, o.as<int>(), nullptr);
+    HIPCHK(hipMemcpy(idx, o.p, 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int wm_op_conv1d_k3(float* out, const float* inp, const float* weight, const float* bias, int C_in, int L_in,
+                               int C_out, int stride, int out_T, int dtype) {
+    if (!out || !inp || !weight || !bias || C_in <= 0 || L_in <= 0 || C_out <= 0) return fail(WM_E_ARG, "bad argument");
+    if (stride != 1 && stride != 2) return fail(WM_E_ARG, "stride must be 1 or 2");
+    if (C_out % 128) return fail(WM_E_ARG, "C_out must be a multiple of 128");
+    if (dtype < 0 || dtype > 2) return fail(WM_E_ARG, "bad dtype");
+    const int Cp = (C_in + 31) / 32 * 32;
+    const int L_out = (L_in + 2 - 3) / stride + 1;
+    TmpDev t;
+    t.bufs.reserve(8);
+    DevBuf &x = t.add(), &xt = t.add(), &w = t.add(), &b = t.add(), &o = t.add(), &o2 = t.add();
+    WMCHK(upload(x, inp, (size_t)C_in * L_in, WM_F32));
+    WMCHK(xt.alloc(((size_t)L_in + 2 + 512) * Cp * dt_size(dtype), true));
+    auto wr = conv_relayout(weight, C_out, C_in, Cp);
+    WMCHK(upload(w, wr.data(), wr.size(), dtype));
+    WMCHK(upload(b, bias, C_out, WM_F32));
+    WMCHK(o.alloc((size_t)L_out * C_out * 4));
+    DISPATCH_DT(dtype, TT, launch_mel_transpose_pad<TT>(x.as<float>(), xt.p, 1, C_in, L_in, Cp, nullptr));
+    GemmParams p{};
+    p.A = xt.p;
+    p.W = w.p;
+    p.C = o.p;
+    p.M = L_out;
+    p.N = C_out;
+    p.K = 3 * Cp;
+    p.lda = (long)stride * Cp;
+    p.ldw = 3 * Cp;
+    p.ldc = C_out;
+    p.bias = b.as<float>();
+    gemm_dispatch(dtype, WM_F32, p, 1, nullptr);
+    if (out_T) {
+        HIPCHK(hipMemcpy(out, o.p, (size_t)L_out * C_out * 4, hipMemcpyDeviceToHost));
+    } else {
+        WMCHK(o2.alloc((size_t)L_out * C_out * 4));
+        launch_transpose_f32(o.as<float>(), o2.as<float>(), L_out, C_out, nullptr);
+        HIPCHK(hipMemcpy(out, o2.p, (size_t)L_out * C_out * 4, hipMemcpyDeviceToHost));
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,107 @@
+// wm_kernels.h — launcher declarations shared by the kernel translation units and the C-ABI host code.
+#pragma once
+#include "wm_device.h"
+
+namespace wm {
+
+// Per-state decode control block, resident in HBM so that a captured decode step can be replayed unchanged.
+struct StepCtl {
+    int len;         // LayerCache.current_len BEFORE this step (= cache row the new K/V is written to)
+    int n_finished;  // utterances that have emitted eot
+    int pad0, pad1;
+};
+
+// ---- encoder ------------------------------------------------------------------------------------------------
+struct GemmParams {
+    const void* A;
+    const void* W;
+    void* C;
+    int M, N, K;  // per batch
+    long lda, ldw, ldc;
+    long strideA, strideC;  // per-batch element strides (grid.z)
+    const float* bias;      // [N] or null
+    const float* residual;  // fp32, indexed [m*ldr + n] (+ z*strideR), or null
+    long ldr, strideR;
+    const float* pos;  // fp32 [M][N] added after the activation (conv2 + pos_emb, whisper.mojo:83-89), or null
+    int act;           // 0 none, 1 gelu
+    int gelu_mode;
+    int group_n;  // >0: column n goes to C + (n/group_n)*group_stride + m*ldc + n%group_n  (cross-K/V scatter)
+    long group_stride;
+};
+template <typename T> void launch_mel_transpose_pad(const float* mel, void* out, int B, int C, int L, int Cp, hipStream_t st);
+template <typename T, typename TO> void launch_gemm_nt(const GemmParams& p, int batch, hipStream_t st);
+template <typename T>
+void launch_layernorm_rows(const float* x, const float* gamma, const float* beta, void* out_t, float* out_f, int rows,
+                           int cols, float eps, hipStream_t st);
+template <typename T> void launch_flash_attn_enc(const void* qkv, void* out, int B, int H, int n_ctx, float scale, hipStream_t st);
+
+// ---- decoder ------------------------------------------------------------------------------------------------
+struct DecLinearParams {
+    const float* x;  // [B][ldx] fp32 activations
+    int ldx;
+    const float* ln_g;  // LayerNorm prologue (null = none)
+    const float* ln_b;
+    const void* W;  // [N][K], operand dtype
+    int N, K, B;
+    const float* bias;  // [N] or null
+    int act, gelu_mode;
+    const float* residual;  // [B][ldr] fp32 or null (may alias out)
+    int ldr;
+    float* out;  // [B][ldo] fp32
+    int ldo;
+    // QKV mode (kcache != null): columns [0,d) -> out (q), [d,2d) -> kcache, [2d,3d) -> vcache at row ctl->len
+    void* kcache;
+    void* vcache;
+    long kv_batch_stride;  // elements between utterances in the cache
+    int d_model;
+    int kv_dtype;  // WM_F32 / WM_BF16 / WM_F16
+    const StepCtl* ctl;
+};
+template <typename TW> void launch_dec_linear(const DecLinearParams& p, hipStream_t st);
+
+struct AttnDecParams {
+    const float* q;  // [B][d] fp32
+    const void* K;   // [B][rows][d] cache of this layer
+    const void* V;
+    long batch_stride;
+    int n_keys;  // >= 0: fixed key count (cross);  < 0: ctl->len + 1 (self, includes the row just written)
+    const StepCtl* ctl;
+    int nsplit;
+    float scale;
+    float* part_o;      // [B][nsplit][d]
+    float* part_ml;     // [B][nsplit][H][2]
+    float* direct_out;  // non-null (nsplit must be 1): write the normalised output [B][d] here, skip the partials
+    int H, d, B;
+};
+template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStream_t st);
+void launch_attn_combine(const float* part_o, const float* part_ml, float* out, int B, int nsplit, int H, int d,
+                         hipStream_t st);
+
+void launch_dec_embed(const float* tok_emb, const float* pos_emb, const int* tok, const int* pos, float* x, int B, int d,
+                      hipStream_t st);
+// argmax over logits rows (lowest index wins) + greedy-loop bookkeeping
+struct ArgmaxParams {
+    const float* logits;
+    int ldl, V, B;
+    int* next;        // [B] next token (also the next step's input)
+    int* out_tokens;  // [B][out_stride] or null
+    int out_stride;
+    int* n_tokens;  // [B]
+    int* finished;  // [B]
+    StepCtl* ctl;
+    int eot, ignore_eot;
+};
+void launch_argmax_step(const ArgmaxParams& p, hipStream_t st);
+void launch_advance(StepCtl* ctl, int* pos, int B, hipStream_t st);
+void launch_set_step(StepCtl* ctl, int len, int set_len, int* pos, int pos_value, int* tok, int tok_value, int B,
+                     hipStream_t st);
+
+// ---- small ops for the op-level C-ABI ----------------------------------------------------------------------------
+void launch_gelu(float* t, size_t n, int mode, hipStream_t st);
+void launch_softmax_rows(float* t, int rows, int cols, hipStream_t st);
+void launch_argmax_plain(const float* t, int n, int* idx, hipStream_t st);
+template <typename T> void launch_convert(const float* in, void* out, size_t n, hipStream_t st);
+template <typename T> void launch_pad_rows(const float* in, void* out, int rows, int cols, int cols_pad, hipStream_t st);
+void launch_transpose_f32(const float* in, float* out, int rows, int cols, hipStream_t st);
+
+}  // namespace wm

@@ -1,0 +1,77 @@
+"""Host-side mirror of /root/reference/whisper_tensor.mojo: the op functions with the reference's names and
+argument meaning (out-param first), each a thin call through the C-ABI into a HIP kernel.  `Tensor` is a
+row-major fp32 numpy array [rows, cols] (whisper_tensor.mojo:10-15)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .config import DT_F32, GELU_TANH
+
+
+def Tensor(rows: int, cols: int) -> np.ndarray:
+    """whisper_tensor.mojo:17-23: zero-filled [rows, cols] fp32."""
+    return np.zeros((rows, cols), np.float32)
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _chk_out(out, shape):
+    if out.dtype != np.float32 or not out.flags.c_contiguous or out.shape != tuple(shape):
+        raise ValueError(f"out must be a C-contiguous float32 array of shape {tuple(shape)}")
+
+
+def matmul(C_out: np.ndarray, A, B, bias=None, dtype=DT_F32):
+    """whisper_tensor.mojo:151-246: C = A·Bᵀ (+bias); B in HF [out,in] layout."""
+    A, B = np.ascontiguousarray(A, np.float32), np.ascontiguousarray(B, np.float32)
+    b = None if bias is None or bias.size == 0 else np.ascontiguousarray(bias, np.float32).ravel()
+    M, K = A.shape
+    N = B.shape[0]
+    _chk_out(C_out, (M, N))
+    _lib.check(_lib.lib().wm_op_matmul_nt(_fp(C_out), _fp(A), _fp(B), _fp(b), M, N, K, dtype))
+
+
+def layer_norm(out: np.ndarray, inp, gamma, beta, eps: float = 1e-5):
+    """whisper_tensor.mojo:249-285"""
+    x = np.ascontiguousarray(inp, np.float32)
+    g, b = np.ascontiguousarray(gamma, np.float32).ravel(), np.ascontiguousarray(beta, np.float32).ravel()
+    _chk_out(out, x.shape)
+    _lib.check(_lib.lib().wm_op_layer_norm(_fp(out), _fp(x), _fp(g), _fp(b), x.shape[0], x.shape[1], eps))
+
+
+def gelu(t: np.ndarray, mode: int = GELU_TANH):
+    """whisper_tensor.mojo:288-308 — in place."""
+    _chk_out(t, t.shape)
+    _lib.check(_lib.lib().wm_op_gelu(_fp(t), t.size, mode))
+
+
+def softmax(t: np.ndarray):
+    """whisper_tensor.mojo:311-355 — rows, in place."""
+    _chk_out(t, t.shape)
+    _lib.check(_lib.lib().wm_op_softmax_rows(_fp(t), t.shape[0], t.shape[1]))
+
+
+def conv1d(out: np.ndarray, inp, weight, bias, stride: int, padding: int = 1, out_T: bool = False, dtype=DT_F32):
+    """whisper_tensor.mojo:367-428 (K=3).  `weight` is the file-layout [C_out, C_in, 3] tensor; the reference's
+    transpose_conv_weights (:358-364) re-layout happens inside the library."""
+    if padding != 1:
+        raise ValueError("the reference only ever uses padding=1 (whisper.mojo:74,79)")
+    x, w = np.ascontiguousarray(inp, np.float32), np.ascontiguousarray(weight, np.float32)
+    b = np.ascontiguousarray(bias, np.float32).ravel()
+    C_in, L_in = x.shape
+    C_out = w.shape[0]
+    L_out = (L_in + 2 - 3) // stride + 1
+    _chk_out(out, (L_out, C_out) if out_T else (C_out, L_out))
+    _lib.check(_lib.lib().wm_op_conv1d_k3(_fp(out), _fp(x), _fp(w), _fp(b), C_in, L_in, C_out, stride, int(out_T), dtype))
+
+
+def argmax(t) -> int:
+    """whisper_tensor.mojo:431-439: lowest index wins ties."""
+    x = np.ascontiguousarray(t, np.float32).ravel()
+    idx = C.c_int32(0)
+    _lib.check(_lib.lib().wm_op_argmax(_fp(x), x.size, C.byref(idx)))
+    return int(idx.value)
