@@ -1,0 +1,335 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle and the committed
+golden fixtures on the same seeded inputs.
+
+Bars (the path is IEEE fp32 except token ids / argmax indices):
+  * token ids and argmax indices: exact, wherever the oracle's top1-top2 margin exceeds the fp32 logit tolerance
+    (greedy argmax is discontinuous; a different summation order may only flip a near-tie, and the test reports it);
+  * fp32 mode: encoder rows and logits within 5e-5 abs of the oracle (values are O(1); different reduction order);
+  * bf16 / f16 operand modes: within 16-bit tolerances written next to each test.
+Nothing here reads /root/reference."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 5e-5
+MARGIN_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from whisper_mojo_amd import _lib
+    _lib.lib()  # raises if the HIP library is missing: no fallback
+    import whisper_mojo_amd as pkg
+    return pkg
+
+
+@pytest.fixture(scope="module")
+def oracle_mod():
+    from oracle import oracle
+    return oracle
+
+
+def make_model(cfg, weights, dtype=0, kv=None, gelu=0, pos=0, max_batch=4):
+    from whisper_mojo_amd.loader import WeightLoader
+    from whisper_mojo_amd.whisper import Whisper
+    m = Whisper(cfg, compute_dtype=dtype, kv_dtype=kv, gelu_mode=gelu, pos_mode=pos, max_batch=max_batch)
+    m.load(WeightLoader.from_array(weights))
+    return m
+
+
+# ---------------------------------------------------------------------------------------------- op-level KATs
+rng = np.random.default_rng(42)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 37, 64), (4, 16, 96), (5, 1037, 384), (64, 256, 384), (200, 128, 96), (130, 384, 1536),
+                                   (17, 50, 32), (70, 24, 128)])
+def test_op_matmul(hip, oracle_mod, M, N, K):
+    from whisper_mojo_amd import whisper_tensor as wt
+    A, B = rng.standard_normal((M, K), np.float32), rng.standard_normal((N, K), np.float32)
+    b = rng.standard_normal(N, np.float32)
+    for bias in (None, b):
+        out = wt.Tensor(M, N)
+        wt.matmul(out, A, B, bias)
+        ref = oracle_mod.matmul(A, B, bias)
+        assert np.abs(out - ref).max() < 1e-5 * K ** 0.5 * 8
+
+
+def test_op_matmul_bf16_rounding(hip):
+    """16-bit operand mode = exact products of the rounded operands (fp32 accumulate)."""
+    import torch
+    from whisper_mojo_amd import whisper_tensor as wt, DT_BF16
+    A, B = rng.standard_normal((64, 384), np.float32), rng.standard_normal((128, 384), np.float32)
+    out = wt.Tensor(64, 128)
+    wt.matmul(out, A, B, None, dtype=DT_BF16)
+    Ab = torch.from_numpy(A).bfloat16().double().numpy()
+    Bb = torch.from_numpy(B).bfloat16().double().numpy()
+    assert np.abs(out - Ab @ Bb.T).max() < 1e-4
+
+
+def test_op_layer_norm(hip, oracle_mod):
+    from whisper_mojo_amd import whisper_tensor as wt
+    for rows, cols in ((9, 384), (1, 128), (70, 512)):
+        x = rng.standard_normal((rows, cols), np.float32) * 3 + 1
+        g, b = rng.standard_normal(cols, np.float32), rng.standard_normal(cols, np.float32)
+        out = wt.Tensor(rows, cols)
+        wt.layer_norm(out, x, g, b)
+        assert np.abs(out - oracle_mod.layer_norm(x, g, b)).max() < 1e-5
+
+
+def test_op_gelu_softmax_argmax(hip, oracle_mod):
+    from whisper_mojo_amd import whisper_tensor as wt
+    t = rng.standard_normal((3, 67), np.float32) * 2
+    for mode in (0, 1):
+        t2 = t.copy()
+        wt.gelu(t2, mode)
+        assert np.abs(t2 - oracle_mod.gelu(t, mode)).max() < 1e-6
+        assert np.array_equal(t2.ravel()[200:], t.ravel()[200:])  # 201 % 8 = 1: tail untouched like the reference
+    for cols in (3, 13, 1500):
+        s = rng.standard_normal((5, cols), np.float32) * 4
+        s2 = s.copy()
+        wt.softmax(s2)
+        assert np.abs(s2 - oracle_mod.softmax(s)).max() < 1e-6
+    v = rng.standard_normal(51865).astype(np.float32)
+    assert wt.argmax(v) == oracle_mod.argmax(v)
+    v[[17, 40000, 51864]] = 9.0  # ties: lowest index wins (whisper_tensor.mojo:436)
+    assert wt.argmax(v) == 17
+
+
+@pytest.mark.parametrize("C_in,L,stride,out_T", [(80, 300, 1, False), (128, 301, 2, True), (16, 64, 2, False), (40, 50, 1, True)])
+def test_op_conv1d(hip, oracle_mod, C_in, L, stride, out_T):
+    from whisper_mojo_amd import whisper_tensor as wt
+    x = rng.standard_normal((C_in, L), np.float32)
+    w = rng.standard_normal((128, C_in, 3), np.float32) * 0.1
+    b = rng.standard_normal(128, np.float32)
+    L_out = (L + 2 - 3) // stride + 1
+    out = wt.Tensor(*((L_out, 128) if out_T else (128, L_out)))
+    wt.conv1d(out, x, w, b, stride, 1, out_T)
+    ref = oracle_mod.conv1d(x, oracle_mod.transpose_conv_weights(w), b, stride, 1, out_T)
+    assert np.abs(out - ref).max() < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------- model-level
+def _first_divergence(got, want):
+    n = min(len(got), len(want))
+    for i in range(n):
+        if got[i] != want[i]:
+            return i
+    return None if len(got) == len(want) else n
+
+
+def _assert_tokens(got, want, logits_ref, n_prompt):
+    """Token-exact unless the oracle itself was at a near-tie where the streams part."""
+    i = _first_divergence(list(got), list(want))
+    if i is None:
+        return
+    s = np.sort(logits_ref[i - n_prompt])
+    margin = s[-1] - s[-2]
+    assert margin < MARGIN_TOL, f"token {i}: HIP {got[i]} vs oracle {want[i]} with oracle margin {margin}"
+
+
+@pytest.mark.parametrize("mode", ["ref", "hf"])
+def test_micro_against_oracle_and_golden(hip, oracle_mod, micro_cfg, micro_weights, mode):
+    from whisper_mojo_amd import synth
+    from whisper_mojo_amd.whisper import KVCache
+    gm, pm = {"ref": (0, 0), "hf": (1, 1)}[mode]
+    g = golden(f"micro_{mode}")
+    mel = synth.synth_mel(micro_cfg, 1000)
+    ref = oracle_mod.OracleModel(micro_cfg, micro_weights, gelu_mode=gm)
+    m = make_model(micro_cfg, micro_weights, gelu=gm, pos=pm)
+    enc = m.encoder.forward(mel)
+    enc_ref = ref.encode(mel)
+    assert np.abs(enc - enc_ref).max() < F32_TOL
+    assert np.abs(enc - g["enc_out"]).max() < F32_TOL
+    # teacher-forced logits, step by step through WhisperDecoder.forward with caller-owned positions
+    forced = g["forced_tokens"]
+    cache = KVCache(m, 1)
+    rows = [m.decoder.forward(forced[:4].tolist(), enc_ref, cache, start_pos=0)]
+    for i in range(4, len(forced)):
+        sp = cache.current_len - 1 if pm == 0 else cache.current_len  # whisper.mojo:217 lives in the host loop
+        rows.append(m.decoder.forward([int(forced[i])], None, cache, start_pos=sp))
+    lg = np.stack(rows)
+    assert np.abs(lg - g["forced_logits"]).max() < F32_TOL
+    assert np.abs(lg - ref.teacher_forced(enc_ref, forced, 4, pm)).max() < F32_TOL
+    assert np.array_equal(lg.argmax(1), g["forced_top_idx"][:, 0])
+    # free-running greedy loop on the device
+    steps = len(forced) - 4
+    got = m.transcribe_batch(mel, prompt=g["prompt"], eot=-1, max_loop=steps)[0]
+    _assert_tokens(got, g["greedy_tokens"], g["greedy_logits"], 4)
+
+
+@pytest.mark.parametrize("mode", ["ref", "hf"])
+def test_tiny_b1_fp32_token_exact(hip, oracle_mod, tiny_cfg, tiny_weights, mode):
+    """BASELINE config 2: Whisper-tiny, batch 1, fp32, greedy — token-exact vs the oracle and the HF-generated golden."""
+    from whisper_mojo_amd import synth
+    gm, pm = {"ref": (0, 0), "hf": (1, 1)}[mode]
+    g = golden(f"tiny_{mode}")
+    mel = synth.synth_mel(tiny_cfg, 1000)
+    m = make_model(tiny_cfg, tiny_weights, gelu=gm, pos=pm, max_batch=1)
+    enc = m.encoder.forward(mel)
+    rows = g["enc_rows"]
+    assert np.abs(enc[rows] - g["enc_out_rows"]).max() < F32_TOL
+    assert np.abs(enc.astype(np.float64).sum(1) - g["enc_out_rowsum"]).max() < 1e-3
+    steps = len(g["forced_tokens"]) - 4
+    got = m.transcribe_batch(mel, max_loop=steps, ignore_eot=True)[0]
+    assert got == g["greedy_tokens"].tolist()  # fixture margins >= 0.014 >> fp32 logit error
+    ref = oracle_mod.OracleModel(tiny_cfg, tiny_weights, gelu_mode=gm)
+    want = ref.transcribe(mel=mel, max_loop=steps, pos_mode=pm, ignore_eot=True)
+    assert got == want.tolist()
+    # teacher-forced top-8 logits vs the golden
+    from whisper_mojo_amd.whisper import KVCache
+    forced = g["forced_tokens"]
+    cache = KVCache(m, 1)
+    m.encoder.forward(mel, cache)
+    lg = [m.decoder.forward(forced[:4].tolist(), None, cache, start_pos=0)]
+    for i in range(4, len(forced)):
+        sp = cache.current_len - 1 if pm == 0 else cache.current_len
+        lg.append(m.decoder.forward([int(forced[i])], None, cache, start_pos=sp))
+    lg = np.stack(lg)
+    assert np.abs(np.take_along_axis(lg, g["forced_top_idx"], 1) - g["forced_top_val"]).max() < F32_TOL
+    assert np.abs(lg[:, :64] - g["forced_logit_slice"]).max() < F32_TOL
+    assert np.array_equal(lg.argmax(1), g["forced_top_idx"][:, 0])
+
+
+def test_batch_equals_singles_and_oracle(hip, oracle_mod, micro_cfg, micro_weights):
+    """The batch dimension the reference lacks: a batch of different mels gives, per utterance, the single-utterance
+    result bit for bit (no cross-utterance state), ragged batch sizes included, and matches the oracle."""
+    from whisper_mojo_amd import synth
+    mels = synth.synth_mels(micro_cfg, 0, 5)
+    m = make_model(micro_cfg, micro_weights, max_batch=5)
+    ref = oracle_mod.OracleModel(micro_cfg, micro_weights)
+    prompt = (1, 2, 3, 4)
+    batch = m.transcribe_batch(mels, prompt=prompt, eot=-1, max_loop=20)
+    enc_b = m.encoder.forward(mels)
+    for b in range(5):
+        single = m.transcribe_batch(mels[b], prompt=prompt, eot=-1, max_loop=20)[0]
+        assert single == batch[b]
+        assert np.array_equal(m.encoder.forward(mels[b]), enc_b[b])
+        want, logits = ref.transcribe(mel=mels[b], prompt=prompt, eot=-1, max_loop=20, want_logits=True)
+        _assert_tokens(batch[b], want, logits, 4)
+    three = m.transcribe_batch(mels[:3], prompt=prompt, eot=-1, max_loop=20)
+    assert three == batch[:3]
+
+
+def test_eot_stop_rule_per_utterance(hip, oracle_mod, micro_cfg, micro_weights):
+    """whisper.mojo:205-221: eot is appended, then that utterance stops; others continue; <= n_prompt+1+max_loop ids."""
+    from whisper_mojo_amd import synth
+    mels = synth.synth_mels(micro_cfg, 0, 4)
+    m = make_model(micro_cfg, micro_weights, max_batch=4)
+    ref = oracle_mod.OracleModel(micro_cfg, micro_weights)
+    prompt = (1, 2, 3, 4)
+    free = m.transcribe_batch(mels, prompt=prompt, eot=-1, max_loop=30)
+    assert all(len(f) == 35 for f in free)
+    eot = free[0][8]  # a token the first utterance emits early
+    got = m.transcribe_batch(mels, prompt=prompt, eot=eot, max_loop=30)
+    for b in range(4):
+        want = ref.transcribe(mel=mels[b], prompt=prompt, eot=eot, max_loop=30)
+        assert got[b] == want.tolist()
+        if eot in free[b][4:]:
+            assert got[b][-1] == eot and got[b].count(eot) == 1 + free[b][:4].count(eot)
+    assert len(got[0]) < 35
+
+
+def test_fixed_mode_ignores_eot(hip, micro_cfg, micro_weights):
+    from whisper_mojo_amd import synth
+    mel = synth.synth_mel(micro_cfg, 1000)
+    m = make_model(micro_cfg, micro_weights)
+    free = m.transcribe_batch(mel, prompt=(1, 2, 3, 4), eot=-1, max_loop=12)[0]
+    fixed = m.transcribe_batch(mel, prompt=(1, 2, 3, 4), eot=free[5], max_loop=12, ignore_eot=True)[0]
+    assert fixed == free
+
+
+def test_device_resident_mel_equals_host_mel(hip, micro_cfg, micro_weights):
+    import torch
+    from whisper_mojo_amd import synth
+    mels = synth.synth_mels(micro_cfg, 3, 2)
+    m = make_model(micro_cfg, micro_weights, max_batch=2)
+    a = m.transcribe_batch(mels, prompt=(1, 2, 3, 4), eot=-1, max_loop=10)
+    b = m.transcribe_batch(torch.from_numpy(mels).cuda(), prompt=(1, 2, 3, 4), eot=-1, max_loop=10)
+    assert a == b
+
+
+@pytest.mark.parametrize("dtype,kv,enc_tol,logit_tol", [(1, 1, 0.06, 0.06), (1, 0, 0.06, 0.06), (2, 2, 0.008, 0.008)])
+def test_tiny_16bit_modes_within_tolerance(hip, oracle_mod, tiny_cfg, tiny_weights, dtype, kv, enc_tol, logit_tol):
+    """BASELINE configs 3 / 5 numerics: 16-bit GEMM operands (bf16: 8-bit mantissa -> ~4e-3 relative per operand;
+    f16: 11-bit) with fp32 accumulation.  Tolerances are absolute on O(1) values (|enc_out| <= 4.3, logit std 1)."""
+    from whisper_mojo_amd import synth
+    from whisper_mojo_amd.whisper import KVCache
+    g = golden("tiny_ref")
+    mel = synth.synth_mel(tiny_cfg, 1000)
+    m = make_model(tiny_cfg, tiny_weights, dtype=dtype, kv=kv, max_batch=1)
+    enc = m.encoder.forward(mel)
+    rows = g["enc_rows"]
+    assert np.abs(enc[rows] - g["enc_out_rows"]).max() < enc_tol
+    forced = g["forced_tokens"]
+    cache = KVCache(m, 1)
+    m.encoder.forward(mel, cache)
+    lg = [m.decoder.forward(forced[:4].tolist(), None, cache, start_pos=0)]
+    for i in range(4, len(forced)):
+        lg.append(m.decoder.forward([int(forced[i])], None, cache, start_pos=cache.current_len - 1))
+    lg = np.stack(lg)
+    err = np.abs(np.take_along_axis(lg, g["forced_top_idx"], 1) - g["forced_top_val"]).max()
+    assert err < logit_tol
+    margins = g["forced_top_val"][:, 0] - g["forced_top_val"][:, 1]
+    clear = margins > 4 * logit_tol
+    assert np.array_equal(lg.argmax(1)[clear], g["forced_top_idx"][clear, 0])
+
+
+def test_base_dims_fp32(hip, oracle_mod):
+    """BASELINE config 5 dims (d_model 512, 8 heads, 6+6 layers, ffn 2048) — the reference cannot run this; a reduced
+    context / vocab keeps the oracle fast."""
+    from whisper_mojo_amd import WhisperConfig, synth
+    cfg = WhisperConfig(512, 8, 6, 3000, 2048, 80, 200, 64)
+    w = synth.synth_weights(cfg, 3)
+    mel = synth.synth_mel(cfg, 1001)
+    ref = oracle_mod.OracleModel(cfg, w)
+    m = make_model(cfg, w, max_batch=1)
+    assert np.abs(m.encoder.forward(mel) - ref.encode(mel)).max() < F32_TOL
+    want, logits = ref.transcribe(mel=mel, prompt=(1, 2, 3, 4), eot=-1, max_loop=16, want_logits=True)
+    got = m.transcribe_batch(mel, prompt=(1, 2, 3, 4), eot=-1, max_loop=16)[0]
+    _assert_tokens(got, want, logits, 4)
+
+
+def test_error_behaviour(hip, micro_cfg, micro_weights):
+    from whisper_mojo_amd import _lib, synth
+    from whisper_mojo_amd.loader import WeightLoader
+    from whisper_mojo_amd.whisper import KVCache, Whisper
+    m = Whisper(micro_cfg)
+    with pytest.raises(_lib.WhisperMiError, match="floats"):
+        m.load(WeightLoader.from_array(micro_weights[:-1]))  # the reference would read past the end (loader.mojo:21-27)
+    with pytest.raises(_lib.WhisperMiError):
+        m.load_file("/nonexistent/whisper_tiny_weights.bin")  # raises like loader.mojo:10-11
+    m = make_model(micro_cfg, micro_weights, max_batch=2)
+    with pytest.raises(_lib.WhisperMiError, match="max_batch"):
+        KVCache(m, 3)
+    cache = KVCache(m, 1)
+    with pytest.raises(_lib.WhisperMiError, match="encoder"):
+        m.decoder.forward([1], None, cache, start_pos=0)
+    with pytest.raises(ValueError):
+        m.transcribe_batch(np.zeros((1, 3, 5), np.float32))
+    mel = synth.synth_mel(micro_cfg, 1000)
+    with pytest.raises(_lib.WhisperMiError, match="context"):
+        m.transcribe_batch(mel, max_loop=500)
+
+
+def test_full_size_properties_b64(hip, tiny_cfg, tiny_weights):
+    """BASELINE config 3 size (B=64, bf16): size-independent properties — batch results equal single-utterance results
+    bit for bit for sampled utterances, every stream has the fixed length, ids are in range, repeat runs are identical."""
+    import ctypes as C
+    from whisper_mojo_amd import _lib
+    L = _lib.lib()
+    mels = np.empty((64, 80, 3000), np.float32)
+    for i in range(64):
+        L.wm_synth_mel_host(1000 + i, 80, 3000, mels[i].ctypes.data_as(C.POINTER(C.c_float)))
+    m = make_model(tiny_cfg, tiny_weights, dtype=1, kv=1, max_batch=64)
+    a = m.transcribe_batch(mels, max_loop=40, ignore_eot=True)
+    b = m.transcribe_batch(mels, max_loop=40, ignore_eot=True)
+    assert a == b
+    assert all(len(t) == 45 and t[:4] == [50258, 50259, 50359, 50363] and max(t) < 51865 and min(t) >= 0 for t in a)
+    for i in (0, 17, 63):
+        assert m.transcribe_batch(mels[i], max_loop=40, ignore_eot=True)[0] == a[i]

@@ -51,7 +51,7 @@ class WhisperConfig:
 
     @staticmethod
     def micro() -> "WhisperConfig":
-        """Reduced test model: same structure, seconds on the CPU oracle."""
+        """Reduced test model: same structure, runs in seconds on a CPU."""
         return WhisperConfig(128, 2, 2, 1000, 512, 16, 100, 64)
 
     @property

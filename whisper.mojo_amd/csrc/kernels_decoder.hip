@@ -387,7 +387,7 @@ __global__ void gelu_kernel(float* t, size_t n, int mode) {
     if (i < n) t[i] = gelu_f(t[i], mode);
 }
 void launch_gelu(float* t, size_t n, int mode, hipStream_t st) {
-    // the reference leaves the tail t.size % width untouched (whisper_tensor.mojo:308); width = 8 as in the oracle
+    // the reference leaves the tail t.size % width untouched (whisper_tensor.mojo:308); width = 8 (x86 AVX2 lanes)
     size_t nb = (n / 8) * 8;
     if (nb) hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, t, nb, mode);
 }

@@ -129,6 +129,7 @@ struct wm_state {
     int out_stride = 0;
     bool has_enc = false, has_cross = false;
     int host_len = 0;
+    const float* last_mel = nullptr;  // device pointer of the last encoded batch (bench replays the encoder on it)
     // encoder arena (sized for Bc utterances)
     DevBuf mel_dev, mel_t, h1, x, xn, qkv, ao, hid, enc_t;
     DevBuf enc_f;            // [B*n_ctx][d] fp32
@@ -410,7 +411,10 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
     s->m = m;
     s->B = B;
     s->Bc = std::min(B, m->enc_chunk);
-    s->nsplit = std::min(32, std::max((int)((T + 511) / 512), (1024 + B - 1) / B));
+    // key chunks per utterance for the cross-attention kernel: independent of B so that an utterance's result does not
+    // depend on how it was batched (bitwise batch invariance); WM_NSPLIT overrides for tuning
+    s->nsplit = std::max((int)((T + 511) / 512), (int)((T + 124) / 125));
+    if (const char* e = getenv("WM_NSPLIT")) s->nsplit = std::max((int)((T + 511) / 512), atoi(e));
     s->out_stride = OUT_STRIDE_MAX;
     const size_t Bc = s->Bc;
     const size_t Mp = (Bc * T + 127) / 128 * 128 + 128;  // padded rows: tail tiles read (never store) past M
@@ -625,6 +629,7 @@ extern "C" int wm_encode(wm_model* m, wm_state* s, const float* mel, int mel_on_
     }
     WMCHK(run_encoder(m, s, mel_dev, B));
     s->has_enc = s->has_cross = true;
+    s->last_mel = mel_dev;
     if (enc_out) HIPCHK(hipMemcpyAsync(enc_out, s->enc_f.p, (size_t)B * c.n_audio_ctx * c.d_model * 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     return 0;
@@ -978,9 +983,10 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
         for (int i = 0; i < reps; ++i) decode_core(m, s, true);
         HIPCHK(hipEventRecord(e1, st));
     } else if (which == WM_KERNEL_ENCODER) {
-        WMCHK(run_encoder(m, s, s->mel_dev.as<float>(), s->B));
+        if (!s->last_mel) return fail(WM_E_STATE, "no mel was encoded into this state");
+        WMCHK(run_encoder(m, s, s->last_mel, s->B));
         HIPCHK(hipEventRecord(e0, st));
-        for (int i = 0; i < reps; ++i) WMCHK(run_encoder(m, s, s->mel_dev.as<float>(), s->B));
+        for (int i = 0; i < reps; ++i) WMCHK(run_encoder(m, s, s->last_mel, s->B));
         HIPCHK(hipEventRecord(e1, st));
     } else {
         return fail(WM_E_ARG, "unknown kernel id %d", which);
