@@ -24,130 +24,314 @@ void launch_dec_embed(const float* tok_emb, const float* pos_emb, const int* tok
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Skinny linear: out[B,N] = epi( pro(x)[B,K] · W[N,K]ᵀ + bias ).  Every weight byte is read from HBM exactly once
-// per step, all B rows sharing the pass — the batched form of the reference's "parallel over n, dot over K" GEMV.
+// Skinny linear: out[B,N] = epi( pro(x)[B,K] · W[N,K]ᵀ + bias ).  Every weight byte is read from HBM once per step,
+// all B rows sharing the pass — the batched form of the reference's "parallel over n, dot over K" GEMV
+// (whisper_tensor.mojo:158-175).
 //
-// Workgroup = 16 output columns; its 4 waves split K (wave w takes k-steps w, w+4, …) and each wave sweeps all
-// row blocks of 16 utterances against the ONE weight fragment it loaded (MFMA 16x16; exact fp32 or 16-bit operands).
-// Computed as outᵀ so a lane owns 4 consecutive columns of one utterance; the 4 K-partials meet in LDS, then wave w
-// finishes row block w (bias / GELU / residual / KV-cache scatter).
-// LayerNorm prologue: the row statistics (one-pass variance, as the reference) are computed by the workgroup for all
-// B rows and applied while the activation fragments are formed, so the normalised vector never exists in memory.
-template <typename TW>
+// These launches move 0.3-1.2 MB each (80 MB for the logits): they are LATENCY bound, so the kernel is shaped so that
+// every global load a wave needs is in flight at once — one dependent HBM round trip per launch:
+//   * workgroup = 16 output columns x NRB row blocks of 16 utterances; its 4 waves split K (wave w owns k-steps
+//     4j+w), so a wave's whole operand set is CH weight fragments + NRB*CH activation fragments, all register resident
+//     (CH = K/128 when that fits, else the K loop runs in chunks of CH k-steps);
+//   * K = d_model launches (CH <= 4) take all 4 row blocks per workgroup (weights fetched once); K = ffn launches take
+//     one row block per workgroup (grid.y = 4; the 3 re-reads of the weight tile hit L2);
+//   * LayerNorm prologue: row statistics (one-pass variance, as the reference) come from the SAME activation
+//     fragments — lane partials, a 4-lane DPP-free butterfly, and one LDS exchange between the 4 K-split waves — so
+//     the normalised vector never exists in memory and nothing is loaded twice;
+//   * computed as outᵀ (A-operand = weight fragment): a lane owns 4 consecutive columns of one utterance; the 4
+//     K-partials meet in LDS, then bias / GELU / residual / KV-cache scatter.
+template <typename TW, int CH, int NRB>
 __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
-    __shared__ float s_mean[64], s_rstd[64];
-    __shared__ __attribute__((aligned(16))) f32x4 s_red[4][4][64];
+    __shared__ float s_stat[4][NRB][16][2];
+    __shared__ __attribute__((aligned(16))) f32x4 s_red[4][NRB][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
+    const int rb0 = blockIdx.y * NRB;
     int wrow = n0 + r16;
     wrow = wrow < p.N ? wrow : p.N - 1;
     const TW* wp = (const TW*)p.W + (size_t)wrow * p.K + g * 8;
-    const int ksteps = p.K >> 5;
-    const int nrb = (p.B + 15) >> 4;
+    const int nch = (p.K >> 7) / CH;  // chunks of CH k-steps per wave
+    const float* xrow[NRB];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+        int row = (rb0 + rb) * 16 + r16;
+        row = row < p.B ? row : p.B - 1;
+        xrow[rb] = p.x + (size_t)row * p.ldx + g * 8;
+    }
+    f32x4 acc[NRB];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int rb0 = 0; rb0 < nrb; rb0 += 4) {
-        const int rows_here = min(64, p.B - rb0 * 16);
-        if (p.ln_g) {
-            __syncthreads();
-            for (int r = w; r < rows_here; r += 4) {
-                const float* xr = p.x + (size_t)(rb0 * 16 + r) * p.ldx;
-                float s = 0.f, q = 0.f;
-                for (int k = lane; k < p.K; k += 64) {
-                    float v = xr[k];
-                    s += v;
-                    q += v * v;
-                }
-                s = wave_sum(s);
-                q = wave_sum(q);
-                const float mean = s / (float)p.K;
-                const float var = (q / (float)p.K) - (mean * mean);
-                if (lane == 0) {
-                    s_mean[r] = mean;
-                    s_rstd[r] = 1.0f / sqrtf(var + 1e-5f);
+    for (int c = 0; c < nch; ++c) {
+        Frag<TW> wf[CH];
+        f32x4 xa[NRB][CH][2];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) wf[i] = load_frag<TW>(wp + ((c * CH + i) * 4 + w) * 32);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const float* xp = xrow[rb] + ((c * CH + i) * 4 + w) * 32;
+                xa[rb][i][0] = *reinterpret_cast<const f32x4*>(xp);
+                xa[rb][i][1] = *reinterpret_cast<const f32x4*>(xp + 4);
+            }
+        float mean[NRB], rstd[NRB];
+        if (p.ln_g) {  // host guarantees nch == 1 here: the fragments cover the whole row
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = xa[rb][i][h2][j];
+                            sm += v;
+                            sq += v * v;
+                        }
+                sm += __shfl_xor(sm, 16, 64);
+                sq += __shfl_xor(sq, 16, 64);
+                sm += __shfl_xor(sm, 32, 64);
+                sq += __shfl_xor(sq, 32, 64);
+                if (g == 0) {
+                    s_stat[w][rb][r16][0] = sm;
+                    s_stat[w][rb][r16][1] = sq;
                 }
             }
             __syncthreads();
-        }
-        f32x4 acc[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int nrb_here = min(4, nrb - rb0);
-        for (int ks = w; ks < ksteps; ks += 4) {
-            const int k = ks * 32 + g * 8;
-            Frag<TW> wf = load_frag<TW>(wp + ks * 32);
+            for (int rb = 0; rb < NRB; ++rb) {
+                const float sm = s_stat[0][rb][r16][0] + s_stat[1][rb][r16][0] + s_stat[2][rb][r16][0] + s_stat[3][rb][r16][0];
+                const float sq = s_stat[0][rb][r16][1] + s_stat[1][rb][r16][1] + s_stat[2][rb][r16][1] + s_stat[3][rb][r16][1];
+                mean[rb] = sm / (float)p.K;
+                const float var = (sq / (float)p.K) - (mean[rb] * mean[rb]);
+                rstd[rb] = 1.0f / sqrtf(var + 1e-5f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
             float gam[8], bet[8];
             if (p.ln_g) {
+                const int k = ((c * CH + i) * 4 + w) * 32 + g * 8;
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.ln_g + k), g1 = *reinterpret_cast<const f32x4*>(p.ln_g + k + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln_b + k), b1 = *reinterpret_cast<const f32x4*>(p.ln_b + k + 4);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    gam[j] = p.ln_g[k + j];
-                    bet[j] = p.ln_b[k + j];
+                for (int j = 0; j < 4; ++j) {
+                    gam[j] = g0[j];
+                    gam[4 + j] = g1[j];
+                    bet[j] = b0[j];
+                    bet[4 + j] = b1[j];
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i < nrb_here) {
-                    int lr = i * 16 + r16;  // row within this pass
-                    lr = lr < rows_here ? lr : rows_here - 1;
-                    const float* xr = p.x + (size_t)(rb0 * 16 + lr) * p.ldx + k;
-                    f32x4 a = *reinterpret_cast<const f32x4*>(xr), b = *reinterpret_cast<const f32x4*>(xr + 4);
-                    float xv[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-                    if (p.ln_g) {
-                        const float mean = s_mean[lr], rstd = s_rstd[lr];
+            for (int rb = 0; rb < NRB; ++rb) {
+                float xv[8];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) xv[j] = (xv[j] - mean) * rstd * gam[j] + bet[j];
-                    }
-                    Frag<TW> xf = make_frag<TW>(xv);
-                    acc[i] = mma32(wf, xf, acc[i]);
+                for (int j = 0; j < 4; ++j) {
+                    xv[j] = xa[rb][i][0][j];
+                    xv[4 + j] = xa[rb][i][1][j];
                 }
+                if (p.ln_g) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[j] = (xv[j] - mean[rb]) * rstd[rb] * gam[j] + bet[j];
+                }
+                acc[rb] = mma32(wf[i], make_frag<TW>(xv), acc[rb]);
             }
         }
-        __syncthreads();
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s_red[w][i][lane] = acc[i];
-        __syncthreads();
-        if (w < nrb_here) {
-            f32x4 v = s_red[0][w][lane] + s_red[1][w][lane] + s_red[2][w][lane] + s_red[3][w][lane];
-            const int lr = w * 16 + r16;
-            if (lr < rows_here) {
-                const int b = rb0 * 16 + lr;
-                const int n = n0 + g * 4;
-                if (p.bias) {
+    for (int rb = 0; rb < NRB; ++rb) s_red[w][rb][lane] = acc[rb];
+    __syncthreads();
+    if (w < NRB) {
+        f32x4 v = s_red[0][w][lane] + s_red[1][w][lane] + s_red[2][w][lane] + s_red[3][w][lane];
+        const int b = (rb0 + w) * 16 + r16;
+        if (b < p.B) {
+            const int n = n0 + g * 4;
+            if (p.bias) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += p.bias[min(n + r, p.N - 1)];
-                }
-                if (p.act) {
+                for (int r = 0; r < 4; ++r) v[r] += p.bias[min(n + r, p.N - 1)];
+            }
+            if (p.act) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], p.gelu_mode);
-                }
-                if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)b * p.ldr + n);
-                if (p.kcache && n >= p.d_model) {
-                    const bool is_v = n >= 2 * p.d_model;
-                    const int c = n - (is_v ? 2 : 1) * p.d_model;
-                    const size_t off = (size_t)b * p.kv_batch_stride + (size_t)p.ctl->len * p.d_model + c;
-                    void* basep = is_v ? p.vcache : p.kcache;
-                    if (p.kv_dtype == 0) {
-                        *reinterpret_cast<f32x4*>((float*)basep + off) = v;
-                    } else if (p.kv_dtype == 1) {
-                        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                        *reinterpret_cast<bf16x4*>((bf16*)basep + off) = o;
-                    } else {
-                        f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                        *reinterpret_cast<f16x4*>((f16*)basep + off) = o;
-                    }
+                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], p.gelu_mode);
+            }
+            if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)b * p.ldr + n);
+            if (p.kcache && n >= p.d_model) {
+                const bool is_v = n >= 2 * p.d_model;
+                const int c = n - (is_v ? 2 : 1) * p.d_model;
+                const size_t off = (size_t)b * p.kv_batch_stride + (size_t)p.ctl->len * p.d_model + c;
+                void* basep = is_v ? p.vcache : p.kcache;
+                if (p.kv_dtype == 0) {
+                    *reinterpret_cast<f32x4*>((float*)basep + off) = v;
+                } else if (p.kv_dtype == 1) {
+                    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    *reinterpret_cast<bf16x4*>((bf16*)basep + off) = o;
                 } else {
-                    *reinterpret_cast<f32x4*>(p.out + (size_t)b * p.ldo + n) = v;
+                    f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                    *reinterpret_cast<f16x4*>((f16*)basep + off) = o;
                 }
+            } else {
+                *reinterpret_cast<f32x4*>(p.out + (size_t)b * p.ldo + n) = v;
             }
         }
     }
 }
+template <typename TW, int CH, int NRB> static void launch_dec_linear_t(const DecLinearParams& p, hipStream_t st) {
+    const int nrb = (p.B + 15) / 16;
+    hipLaunchKernelGGL((dec_linear_kernel<TW, CH, NRB>), dim3((p.N + 15) / 16, (nrb + NRB - 1) / NRB), dim3(256), 0, st, p);
+}
+// K % 128 == 0.  kpw = k-steps per wave = K/128.
 template <typename TW> void launch_dec_linear(const DecLinearParams& p, hipStream_t st) {
-    hipLaunchKernelGGL(dec_linear_kernel<TW>, dim3((p.N + 15) / 16), dim3(256), 0, st, p);
+    const int kpw = p.K >> 7;
+    constexpr bool W32 = sizeof(TW) == 4;
+    switch (kpw) {
+        case 1: return launch_dec_linear_t<TW, 1, 4>(p, st);
+        case 2: return launch_dec_linear_t<TW, 2, 4>(p, st);
+        case 3: return launch_dec_linear_t<TW, 3, 4>(p, st);
+        case 4: return launch_dec_linear_t<TW, 4, 4>(p, st);
+        default: break;
+    }
+    if (!W32 && kpw % 12 == 0) return launch_dec_linear_t<TW, 12, 1>(p, st);
+    if (kpw % 8 == 0) return launch_dec_linear_t<TW, 8, 1>(p, st);
+    if (kpw % 6 == 0) return launch_dec_linear_t<TW, 6, 1>(p, st);
+    if (kpw % 4 == 0) return launch_dec_linear_t<TW, 4, 1>(p, st);
+    if (kpw % 3 == 0) return launch_dec_linear_t<TW, 3, 1>(p, st);
+    return launch_dec_linear_t<TW, 1, 1>(p, st);
 }
 template void launch_dec_linear<float>(const DecLinearParams&, hipStream_t);
 template void launch_dec_linear<bf16>(const DecLinearParams&, hipStream_t);
 template void launch_dec_linear<f16>(const DecLinearParams&, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------------------
+// Final LayerNorm + tied-embedding logits (whisper.mojo:156-166): logits[B, V] = LN(x)[B, d] · tok_emb[V, d]ᵀ.
+// 80 MB (fp32) / 40 MB (16-bit) of weights per step: the one decoder GEMM that is bandwidth- rather than
+// latency-bound.  Workgroup = 128 vocabulary rows x up to 64 utterances: the normalised activations are built ONCE per
+// workgroup (LN statistics from a 4-thread-per-row sweep, everything in flight at once) and parked in LDS as MFMA
+// operands, so L2 sees x once per 128 columns; each wave then streams its 32 embedding rows straight from HBM into
+// registers (all k-steps in flight) and needs no cross-wave reduction.
+template <typename TW, int KD /* d_model/128 */, int NRB>
+__global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
+    constexpr int K = KD * 128;
+    constexpr int PAD = 16 / sizeof(TW);
+    constexpr int PITCH = K + PAD;
+    constexpr int KS = KD * 4;                         // k-steps of 32
+    constexpr int CHK = sizeof(TW) == 2 ? KS : KS / 2;  // k-steps whose weight fragments are in flight together
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    TW* xs = reinterpret_cast<TW*>(smem_raw);  // [NRB*16][PITCH]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.y * NRB * 16;
+    const int nrows = min(NRB * 16, p.B - row0);
+
+    {  // LN + convert -> LDS.  thread t: row t>>2 (+64 per pass), quarter t&3 of the row, float4 index q + 4*i
+        for (int rbase = 0; rbase < NRB * 16; rbase += 64) {
+            const int lr = rbase + (threadIdx.x >> 2), q = threadIdx.x & 3;
+            if (lr < NRB * 16) {
+                const int row = min(lr, nrows - 1);
+                const float* xr = p.x + (size_t)(row0 + row) * p.ldx;
+                f32x4 v[KD * 8];
+#pragma unroll
+                for (int i = 0; i < KD * 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * (q + 4 * i));
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int i = 0; i < KD * 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        sm += v[i][j];
+                        sq += v[i][j] * v[i][j];
+                    }
+                sm += __shfl_xor(sm, 1, 64);
+                sq += __shfl_xor(sq, 1, 64);
+                sm += __shfl_xor(sm, 2, 64);
+                sq += __shfl_xor(sq, 2, 64);
+                const float mean = sm / (float)K;
+                const float var = (sq / (float)K) - (mean * mean);
+                const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+                for (int i = 0; i < KD * 8; ++i) {
+                    const int k = 4 * (q + 4 * i);
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(p.ln_g + k), bt = *reinterpret_cast<const f32x4*>(p.ln_b + k);
+                    typedef __attribute__((ext_vector_type(4))) TW t4;
+                    t4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = from_f32<TW>((v[i][j] - mean) * rstd * gm[j] + bt[j]);
+                    *reinterpret_cast<t4*>(&xs[lr * PITCH + k]) = o;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int n0 = blockIdx.x * 128 + w * 32;
+    const TW* wp[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        int wr = n0 + nb * 16 + r16;
+        wr = wr < p.N ? wr : p.N - 1;
+        wp[nb] = (const TW*)p.W + (size_t)wr * K + g * 8;
+    }
+    f32x4 acc[2][NRB];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc[nb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KS / CHK; ++c) {
+        Frag<TW> wf[2][CHK];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + (c * CHK + i) * 32);
+#pragma unroll
+        for (int i = 0; i < CHK; ++i) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                Frag<TW> xf = load_frag<TW>(&xs[(rb * 16 + r16) * PITCH + (c * CHK + i) * 32 + g * 8]);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) acc[nb][rb] = mma32(wf[nb][i], xf, acc[nb][rb]);
+            }
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+        const int lr = rb * 16 + r16;
+        if (lr < nrows) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int n = n0 + nb * 16 + g * 4;
+                if (n < p.ldo) *reinterpret_cast<f32x4*>(p.out + (size_t)(row0 + lr) * p.ldo + n) = acc[nb][rb];
+            }
+        }
+    }
+}
+template <typename TW, int KD, int NRB> static void launch_dec_logits_t(const DecLinearParams& p, hipStream_t st) {
+    const size_t lds = (size_t)NRB * 16 * (KD * 128 + 16 / sizeof(TW)) * sizeof(TW);
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_logits_kernel<TW, KD, NRB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((p.N + 127) / 128, (p.B + NRB * 16 - 1) / (NRB * 16));
+    hipLaunchKernelGGL((dec_logits_kernel<TW, KD, NRB>), grid, dim3(256), lds, st, p);
+}
+// requires ln_g/ln_b, no bias/act/residual, K in {128, 384, 512}, ldo % 4 == 0
+template <typename TW> void launch_dec_logits(const DecLinearParams& p, hipStream_t st) {
+    const int kd = p.K >> 7;
+    if (p.B <= 16) {
+        if (kd == 1) return launch_dec_logits_t<TW, 1, 1>(p, st);
+        if (kd == 3) return launch_dec_logits_t<TW, 3, 1>(p, st);
+        return launch_dec_logits_t<TW, 4, 1>(p, st);
+    }
+    if (kd == 1) return launch_dec_logits_t<TW, 1, 4>(p, st);
+    if (kd == 3) return launch_dec_logits_t<TW, 3, 4>(p, st);
+    return launch_dec_logits_t<TW, 4, 4>(p, st);
+}
+template void launch_dec_logits<float>(const DecLinearParams&, hipStream_t);
+template void launch_dec_logits<bf16>(const DecLinearParams&, hipStream_t);
+template void launch_dec_logits<f16>(const DecLinearParams&, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------------------
 // Single-query attention over the KV cache (layers.mojo:186-272), all heads of one utterance per workgroup so that
@@ -272,68 +456,94 @@ template void launch_attn_decode<float>(const AttnDecParams&, hipStream_t);
 template void launch_attn_decode<bf16>(const AttnDecParams&, hipStream_t);
 template void launch_attn_decode<f16>(const AttnDecParams&, hipStream_t);
 
-// merge the key-chunk partials: out[b][h*64+e] = Σ_s w_s·o_s / Σ_s w_s·l_s,  w_s = exp(m_s − max m)
+// merge the key-chunk partials: out[b][h*64+e] = Σ_s w_s·o_s / Σ_s w_s·l_s,  w_s = exp(m_s − max m).
+// One wave per (utterance, head): lane s owns chunk s's (m, l) — one exp per chunk, not per element — and the
+// weights reach the 64 output lanes by wave broadcast.  nsplit <= 64.
 __global__ void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                     float* __restrict__ out, int nsplit, int H, int d) {
-    const int b = blockIdx.x;
-    for (int t = threadIdx.x; t < d; t += blockDim.x) {
-        const int h = t >> 6;
-        float M = -1e30f;
-        for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_ml[(((size_t)b * nsplit + s) * H + h) * 2]);
-        float L = 0.f, o = 0.f;
-        for (int s = 0; s < nsplit; ++s) {
-            const float* ml = part_ml + (((size_t)b * nsplit + s) * H + h) * 2;
-            const float wgt = ml[1] > 0.f ? expf(ml[0] - M) : 0.f;
-            L += wgt * ml[1];
-            o += wgt * part_o[((size_t)b * nsplit + s) * d + t];
-        }
-        out[(size_t)b * d + t] = o * (1.0f / L);
+    const int b = blockIdx.x, lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+    float m = -1e30f, l = 0.f;
+    if (lane < nsplit) {
+        const float* ml = part_ml + (((size_t)b * nsplit + lane) * H + h) * 2;
+        m = ml[0];
+        l = ml[1];
     }
+    const float M = wave_max(l > 0.f ? m : -1e30f);
+    const float wgt = l > 0.f ? expf(m - M) : 0.f;
+    const float L = wave_sum(wgt * l);
+    const float* po = part_o + (size_t)b * nsplit * d + h * 64 + lane;
+    float o = 0.f;
+    for (int s = 0; s < nsplit; ++s) o += __shfl(wgt, s, 64) * po[(size_t)s * d];
+    out[(size_t)b * d + h * 64 + lane] = o * (1.0f / L);
 }
 void launch_attn_combine(const float* part_o, const float* part_ml, float* out, int B, int nsplit, int H, int d,
                          hipStream_t st) {
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(B), dim3(d < 256 ? 128 : 256), 0, st, part_o, part_ml, out, nsplit, H, d);
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(B), dim3(64 * H), 0, st, part_o, part_ml, out, nsplit, H, d);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // argmax with the reference's tie rule (strict '>' scanning upward => lowest index wins, whisper_tensor.mojo:436)
 // + the greedy loop's bookkeeping (whisper.mojo:200-221): append the id, stop an utterance after its eot.
+// block-wide (value, index) argmax of row[0..V): 16-byte loads (row 16-byte aligned, V rounded up inside the padded
+// row), every load independent; ties resolve to the LOWEST index at every level.
 __device__ __forceinline__ void argmax_block(const float* row, int V, float& best, int& bidx) {
-    __shared__ float s_v[256];
-    __shared__ int s_i[256];
+    __shared__ float s_v[16];
+    __shared__ int s_i[16];
     float mv = -INFINITY;
     int mi = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += blockDim.x) {
-        float v = row[i];
+    const int nv = V >> 2;
+    for (int i = threadIdx.x; i < nv; i += blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (v[j] > mv) {  // increasing index within a thread: strict '>' keeps the lowest
+                mv = v[j];
+                mi = 4 * i + j;
+            }
+    }
+    for (int i = (nv << 2) + threadIdx.x; i < V; i += blockDim.x) {
+        const float v = row[i];
         if (v > mv || (v == mv && i < mi)) {
             mv = v;
             mi = i;
         }
     }
-    s_v[threadIdx.x] = mv;
-    s_i[threadIdx.x] = mi;
-    __syncthreads();
-    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
-        if (threadIdx.x < o) {
-            float v2 = s_v[threadIdx.x + o];
-            int i2 = s_i[threadIdx.x + o];
-            if (v2 > s_v[threadIdx.x] || (v2 == s_v[threadIdx.x] && i2 < s_i[threadIdx.x])) {
-                s_v[threadIdx.x] = v2;
-                s_i[threadIdx.x] = i2;
-            }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(mv, o, 64);
+        const int i2 = __shfl_xor(mi, o, 64);
+        if (v2 > mv || (v2 == mv && i2 < mi)) {
+            mv = v2;
+            mi = i2;
         }
-        __syncthreads();
     }
-    best = s_v[0];
-    bidx = s_i[0];
+    const int wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_v[wid] = mv;
+        s_i[wid] = mi;
+    }
+    __syncthreads();
+    mv = s_v[0];
+    mi = s_i[0];
+    for (int k = 1; k < nw; ++k)
+        if (s_v[k] > mv || (s_v[k] == mv && s_i[k] < mi)) {
+            mv = s_v[k];
+            mi = s_i[k];
+        }
+    best = mv;
+    bidx = mi;
 }
-__global__ __launch_bounds__(256) void argmax_step_kernel(ArgmaxParams p) {
+__global__ __launch_bounds__(1024) void argmax_step_kernel(ArgmaxParams p) {
     const int b = blockIdx.x;
     float best;
     int idx;
     argmax_block(p.logits + (size_t)b * p.ldl, p.V, best, idx);
     if (threadIdx.x == 0) {
         p.next[b] = idx;
+        if (p.advance) {  // current_len += 1 (layers.mojo:143), position += 1: nothing else in this launch reads them
+            p.pos[b] += 1;
+            if (b == 0) p.ctl->len += 1;
+        }
         if (p.out_tokens && !p.finished[b]) {
             p.out_tokens[(size_t)b * p.out_stride + p.n_tokens[b]] = idx;
             p.n_tokens[b] += 1;
@@ -345,16 +555,16 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(ArgmaxParams p) {
     }
 }
 void launch_argmax_step(const ArgmaxParams& p, hipStream_t st) {
-    hipLaunchKernelGGL(argmax_step_kernel, dim3(p.B), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(argmax_step_kernel, dim3(p.B), dim3(1024), 0, st, p);
 }
-__global__ __launch_bounds__(256) void argmax_plain_kernel(const float* t, int n, int* idx) {
+__global__ __launch_bounds__(1024) void argmax_plain_kernel(const float* t, int n, int* idx) {
     float best;
     int i;
     argmax_block(t, n, best, i);
     if (threadIdx.x == 0) *idx = i;
 }
 void launch_argmax_plain(const float* t, int n, int* idx, hipStream_t st) {
-    hipLaunchKernelGGL(argmax_plain_kernel, dim3(1), dim3(256), 0, st, t, n, idx);
+    hipLaunchKernelGGL(argmax_plain_kernel, dim3(1), dim3(1024), 0, st, t, n, idx);
 }
 
 // current_len += 1 (layers.mojo:143) and every utterance's position += 1

@@ -129,6 +129,8 @@ struct wm_state {
     int out_stride = 0;
     bool has_enc = false, has_cross = false;
     int host_len = 0;
+    hipGraphExec_t step_graph = nullptr;  // captured [decode step + argmax + advance]; replayed once per token
+    int graph_eot = 0, graph_ignore = 0;
     const float* last_mel = nullptr;  // device pointer of the last encoded batch (bench replays the encoder on it)
     // encoder arena (sized for Bc utterances)
     DevBuf mel_dev, mel_t, h1, x, xn, qkv, ao, hid, enc_t;
@@ -391,6 +393,7 @@ extern "C" int wm_model_load(const char* path, const wm_config* cfg, int device,
 extern "C" void wm_state_free(wm_state* s) {
     if (!s) return;
     (void)hipSetDevice(s->m->device);
+    if (s->step_graph) (void)hipGraphExecDestroy(s->step_graph);
     DevBuf* bs[] = {&s->mel_dev, &s->mel_t, &s->h1, &s->x, &s->xn, &s->qkv, &s->ao, &s->hid, &s->enc_t, &s->enc_f,
                     &s->cross_kv, &s->self_kv, &s->dx, &s->dq, &s->dattn, &s->dhid, &s->part_o, &s->part_ml, &s->logits,
                     &s->tok, &s->pos, &s->ctl, &s->out_tokens, &s->n_tokens, &s->finished};
@@ -798,11 +801,11 @@ static void decode_core(wm_model* m, wm_state* s, bool want_logits) {
         p.B = B;
         p.out = s->logits.as<float>();
         p.ldo = m->Vpad;
-        dec_linear_dispatch(T, p, st);
+        DISPATCH_DT(T, TT, launch_dec_logits<TT>(p, st));
     }
 }
 
-static ArgmaxParams argmax_params(wm_model* m, wm_state* s, bool record, int eot, int ignore_eot) {
+static ArgmaxParams argmax_params(wm_model* m, wm_state* s, bool record, int eot, int ignore_eot, bool advance = false) {
     ArgmaxParams a{};
     a.logits = s->logits.as<float>();
     a.ldl = m->Vpad;
@@ -816,6 +819,8 @@ static ArgmaxParams argmax_params(wm_model* m, wm_state* s, bool record, int eot
     a.ctl = s->ctl.as<StepCtl>();
     a.eot = eot;
     a.ignore_eot = ignore_eot;
+    a.advance = advance ? 1 : 0;
+    a.pos = s->pos.as<int>();
     return a;
 }
 
@@ -882,6 +887,23 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o) 
     // incremental steps: start_pos = current_len - 1 (reference, :217) or current_len (HF)
     const int first_pos = o->pos_mode == WM_POS_REF ? o->n_prompt - 1 : o->n_prompt;
     launch_set_step(ctl, o->n_prompt, 1, s->pos.as<int>(), first_pos, nullptr, 0, B, st);
+    // steady state: one captured graph = [39 decode-step launches + argmax/bookkeeping]; every per-step quantity
+    // (token, position, cache length) lives in HBM, so the same graph is replayed for every token
+    static const bool no_graph = getenv("WM_NO_GRAPH") != nullptr;
+    if (!no_graph && (!s->step_graph || s->graph_eot != o->eot || s->graph_ignore != o->ignore_eot)) {
+        if (s->step_graph) (void)hipGraphExecDestroy(s->step_graph);
+        s->step_graph = nullptr;
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        decode_core(m, s, true);
+        launch_argmax_step(argmax_params(m, s, true, o->eot, o->ignore_eot, true), st);
+        HIPCHK(hipStreamEndCapture(st, &g));
+        hipError_t ge = hipGraphInstantiate(&s->step_graph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ge != hipSuccess) return fail(WM_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ge));
+        s->graph_eot = o->eot;
+        s->graph_ignore = o->ignore_eot;
+    }
     StepCtl* h_ctl = nullptr;
     HIPCHK(hipHostMalloc((void**)&h_ctl, sizeof(StepCtl), 0));
     int rc = 0;
@@ -895,9 +917,16 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o) 
             }
             if (h_ctl->n_finished >= B) break;
         }
-        decode_core(m, s, true);
-        launch_argmax_step(argmax_params(m, s, true, o->eot, o->ignore_eot), st);
-        launch_advance(ctl, s->pos.as<int>(), B, st);
+        if (s->step_graph && !no_graph) {
+            hipError_t e = hipGraphLaunch(s->step_graph, st);
+            if (e != hipSuccess) {
+                rc = fail(WM_E_HIP, "hipGraphLaunch: %s", hipGetErrorString(e));
+                break;
+            }
+        } else {
+            decode_core(m, s, true);
+            launch_argmax_step(argmax_params(m, s, true, o->eot, o->ignore_eot, true), st);
+        }
     }
     (void)hipHostFree(h_ctl);
     if (rc) return rc;
@@ -979,9 +1008,20 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
         const int len0 = std::max(s->host_len, 1);
         launch_set_step(s->ctl.as<StepCtl>(), len0, 1, nullptr, 0, nullptr, 0, s->B, st);
         decode_core(m, s, true);
+        // timed as the transcribe loop runs it: a captured graph of the step, replayed (cache length held constant)
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        decode_core(m, s, true);
+        HIPCHK(hipStreamEndCapture(st, &g));
+        HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+        HIPCHK(hipGraphLaunch(ge, st));
         HIPCHK(hipEventRecord(e0, st));
-        for (int i = 0; i < reps; ++i) decode_core(m, s, true);
+        for (int i = 0; i < reps; ++i) HIPCHK(hipGraphLaunch(ge, st));
         HIPCHK(hipEventRecord(e1, st));
+        HIPCHK(hipEventSynchronize(e1));
+        (void)hipGraphExecDestroy(ge);
     } else if (which == WM_KERNEL_ENCODER) {
         if (!s->last_mel) return fail(WM_E_STATE, "no mel was encoded into this state");
         WMCHK(run_encoder(m, s, s->last_mel, s->B));
@@ -1043,9 +1083,14 @@ extern "C" int wm_op_matmul_nt(float* C, const float* A, const float* Bm, const 
         HIPCHK(hipMemcpy(C, c.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     } else {  // skinny path: the decode-step linear kernel
         const int Np = (N + 15) / 16 * 16;
+        const int Kp = (K + 127) / 128 * 128;  // the kernel splits K over 4 waves in 32-deep steps: zero-pad K
+        std::vector<float> Apad((size_t)M * Kp, 0.f), Bpad((size_t)N * Kp, 0.f);
+        for (int i = 0; i < M; ++i) memcpy(&Apad[(size_t)i * Kp], A + (size_t)i * K, (size_t)K * 4);
+        for (int i = 0; i < N; ++i) memcpy(&Bpad[(size_t)i * Kp], Bm + (size_t)i * K, (size_t)K * 4);
+        K = Kp;
         DevBuf &a = t.add(), &w = t.add(), &c = t.add(), &b = t.add();
-        WMCHK(upload(a, A, (size_t)M * K, WM_F32));
-        WMCHK(upload(w, Bm, (size_t)N * K, dtype));
+        WMCHK(upload(a, Apad.data(), Apad.size(), WM_F32));
+        WMCHK(upload(w, Bpad.data(), Bpad.size(), dtype));
         WMCHK(c.alloc((size_t)M * Np * 4));
         if (bias) WMCHK(upload(b, bias, N, WM_F32));
         DecLinearParams p{};

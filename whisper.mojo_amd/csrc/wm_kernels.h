@@ -58,6 +58,7 @@ struct DecLinearParams {
     const StepCtl* ctl;
 };
 template <typename TW> void launch_dec_linear(const DecLinearParams& p, hipStream_t st);
+template <typename TW> void launch_dec_logits(const DecLinearParams& p, hipStream_t st);
 
 struct AttnDecParams {
     const float* q;  // [B][d] fp32
@@ -90,6 +91,8 @@ struct ArgmaxParams {
     int* finished;  // [B]
     StepCtl* ctl;
     int eot, ignore_eot;
+    int advance;  // != 0: also do the end-of-step bookkeeping (len += 1, pos[b] += 1)
+    int* pos;
 };
 void launch_argmax_step(const ArgmaxParams& p, hipStream_t st);
 void launch_advance(StepCtl* ctl, int* pos, int B, hipStream_t st);
