@@ -63,9 +63,28 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Epilogue operands are requested FIRST so they ride the same memory round trip as the weights: each later
+    // dependent global load would add ~1 us to a ~5 us launch.
+    const int eb = (rb0 + (w < NRB ? w : 0)) * 16 + r16;  // utterance / column quad this lane finishes
+    const int en = n0 + g * 4;
+    const bool epi = w < NRB && eb < p.B;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 res4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cache_row = 0;
+    if (epi) {
+        if (p.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias4[r] = p.bias[min(en + r, p.N - 1)];
+        }
+        if (p.residual) res4 = *reinterpret_cast<const f32x4*>(p.residual + (size_t)eb * p.ldr + en);
+        if (p.kcache) cache_row = p.ctl->len;
+    }
+    constexpr bool EARLY_GB = sizeof(TW) == 2 || CH <= 3;  // keep LN gamma/beta in registers when they fit
+
     for (int c = 0; c < nch; ++c) {
         Frag<TW> wf[CH];
         f32x4 xa[NRB][CH][2];
+        f32x4 gb[EARLY_GB ? CH : 1][4];
 #pragma unroll
         for (int i = 0; i < CH; ++i) wf[i] = load_frag<TW>(wp + ((c * CH + i) * 4 + w) * 32);
 #pragma unroll
@@ -76,6 +95,16 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
                 xa[rb][i][0] = *reinterpret_cast<const f32x4*>(xp);
                 xa[rb][i][1] = *reinterpret_cast<const f32x4*>(xp + 4);
             }
+        if (EARLY_GB && p.ln_g) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int k = ((c * CH + i) * 4 + w) * 32 + g * 8;
+                gb[i][0] = *reinterpret_cast<const f32x4*>(p.ln_g + k);
+                gb[i][1] = *reinterpret_cast<const f32x4*>(p.ln_g + k + 4);
+                gb[i][2] = *reinterpret_cast<const f32x4*>(p.ln_b + k);
+                gb[i][3] = *reinterpret_cast<const f32x4*>(p.ln_b + k + 4);
+            }
+        }
         float mean[NRB], rstd[NRB];
         if (p.ln_g) {  // host guarantees nch == 1 here: the fragments cover the whole row
 #pragma unroll
@@ -114,9 +143,19 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
         for (int i = 0; i < CH; ++i) {
             float gam[8], bet[8];
             if (p.ln_g) {
-                const int k = ((c * CH + i) * 4 + w) * 32 + g * 8;
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.ln_g + k), g1 = *reinterpret_cast<const f32x4*>(p.ln_g + k + 4);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln_b + k), b1 = *reinterpret_cast<const f32x4*>(p.ln_b + k + 4);
+                f32x4 g0, g1, b0, b1;
+                if (EARLY_GB) {
+                    g0 = gb[i][0];
+                    g1 = gb[i][1];
+                    b0 = gb[i][2];
+                    b1 = gb[i][3];
+                } else {
+                    const int k = ((c * CH + i) * 4 + w) * 32 + g * 8;
+                    g0 = *reinterpret_cast<const f32x4*>(p.ln_g + k);
+                    g1 = *reinterpret_cast<const f32x4*>(p.ln_g + k + 4);
+                    b0 = *reinterpret_cast<const f32x4*>(p.ln_b + k);
+                    b1 = *reinterpret_cast<const f32x4*>(p.ln_b + k + 4);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     gam[j] = g0[j];
@@ -144,37 +183,31 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) s_red[w][rb][lane] = acc[rb];
     __syncthreads();
-    if (w < NRB) {
+    if (epi) {
         f32x4 v = s_red[0][w][lane] + s_red[1][w][lane] + s_red[2][w][lane] + s_red[3][w][lane];
-        const int b = (rb0 + w) * 16 + r16;
-        if (b < p.B) {
-            const int n = n0 + g * 4;
-            if (p.bias) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += p.bias[min(n + r, p.N - 1)];
-            }
-            if (p.act) {
+        for (int r = 0; r < 4; ++r) v[r] += bias4[r];
+        if (p.act) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], p.gelu_mode);
-            }
-            if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)b * p.ldr + n);
-            if (p.kcache && n >= p.d_model) {
-                const bool is_v = n >= 2 * p.d_model;
-                const int c = n - (is_v ? 2 : 1) * p.d_model;
-                const size_t off = (size_t)b * p.kv_batch_stride + (size_t)p.ctl->len * p.d_model + c;
-                void* basep = is_v ? p.vcache : p.kcache;
-                if (p.kv_dtype == 0) {
-                    *reinterpret_cast<f32x4*>((float*)basep + off) = v;
-                } else if (p.kv_dtype == 1) {
-                    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                    *reinterpret_cast<bf16x4*>((bf16*)basep + off) = o;
-                } else {
-                    f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                    *reinterpret_cast<f16x4*>((f16*)basep + off) = o;
-                }
+            for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], p.gelu_mode);
+        }
+        v += res4;
+        if (p.kcache && en >= p.d_model) {
+            const bool is_v = en >= 2 * p.d_model;
+            const int cc = en - (is_v ? 2 : 1) * p.d_model;
+            const size_t off = (size_t)eb * p.kv_batch_stride + (size_t)cache_row * p.d_model + cc;
+            void* basep = is_v ? p.vcache : p.kcache;
+            if (p.kv_dtype == 0) {
+                *reinterpret_cast<f32x4*>((float*)basep + off) = v;
+            } else if (p.kv_dtype == 1) {
+                bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                *reinterpret_cast<bf16x4*>((bf16*)basep + off) = o;
             } else {
-                *reinterpret_cast<f32x4*>(p.out + (size_t)b * p.ldo + n) = v;
+                f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                *reinterpret_cast<f16x4*>((f16*)basep + off) = o;
             }
+        } else {
+            *reinterpret_cast<f32x4*>(p.out + (size_t)eb * p.ldo + en) = v;
         }
     }
 }
@@ -337,20 +370,23 @@ template void launch_dec_logits<f16>(const DecLinearParams&, hipStream_t);
 // Single-query attention over the KV cache (layers.mojo:186-272), all heads of one utterance per workgroup so that
 // whole token-major cache rows (H*64 elements, the reference's layout: layers.mojo:140-147) stream fully coalesced.
 // grid = (nsplit key chunks, B).  Lane map: LPH lanes (16 B each) cover one head's 64 dims of one key; LPR = H*LPH
-// lanes cover a row; the block sweeps RPS rows per step.  Dot products reduce inside an aligned LPH-lane group with
-// DPP only.  Two passes over the chunk (K, then V) with scores parked in LDS; every K and V byte is read once.
-// Emits un-normalised partials (o, max, sum) per chunk; attn_combine merges chunks.
+// lanes cover a row; the block sweeps RPS rows per step, U steps per iteration.
+// ONE pass: K and V rows of an iteration are requested together (and the next iteration's before this one is
+// consumed), scores reduce inside an aligned LPH-lane group with DPP only, and the softmax is the online form
+// (running max / sum per lane, one rescale per iteration) — every K and V byte is read once, nothing is parked in LDS
+// except the final merge of the RPS row slots.  Emits un-normalised partials (o, max, sum) per chunk for
+// attn_combine, or the normalised output directly when the chunk is the whole sequence.
 // Scale after the dot product and max initialised to -1e10 follow layers.mojo:196,212 (the mask branch at :213 is a
 // no-op for j <= len-1 and is omitted).
-template <typename TKV, int LPH>
+template <typename TKV, int LPH, bool FAST>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecParams p) {
     constexpr int EPL = 64 / LPH;  // elements per lane
-    __shared__ float s_scores[512 * 8];
-    __shared__ float s_m[8], s_l[8];
+    constexpr int U = 4;
+    __shared__ float s_ml[256][2];
     __shared__ float s_red[256 * EPL];
     const int b = blockIdx.y, split = blockIdx.x;
     const int LPR = p.H * LPH;
-    const int RPS = blockDim.x / LPR;
+    const int RPS = 256 / LPR;
     const int len = p.n_keys >= 0 ? p.n_keys : p.ctl->len + 1;
     const int chunk = (len + p.nsplit - 1) / p.nsplit;
     const int j0 = split * chunk;
@@ -358,99 +394,113 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecParams p) {
     const int rslot = threadIdx.x / LPR, c = threadIdx.x % LPR;
     const int h = c / LPH, e0 = (c % LPH) * EPL;
     const bool active = rslot < RPS;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
 
     float qv[EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) qv[e] = p.q[(size_t)b * p.d + h * 64 + e0 + e];
+    for (int e = 0; e < EPL; ++e) qv[e] = p.q[(size_t)b * p.d + h * 64 + e0 + e] * p.scale;
     const TKV* Kb = (const TKV*)p.K + (size_t)b * p.batch_stride + h * 64 + e0;
     const TKV* Vb = (const TKV*)p.V + (size_t)b * p.batch_stride + h * 64 + e0;
     typedef __attribute__((ext_vector_type(EPL))) TKV kvec;
 
-    // pass 1: scores
-    constexpr int U = 4;
-    for (int j = j0 + rslot; j < j1; j += RPS * U) {
-        kvec kv[U];
+    float m_run = -1e10f, l_run = 0.f;
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    const int step = RPS * U;
+
+    auto load = [&](kvec (&kk)[U], kvec (&vv)[U], int j) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int jj = min(j + u * RPS, j1 - 1);
-            kv[u] = *reinterpret_cast<const kvec*>(Kb + (size_t)jj * p.d);
+            const int jj = max(min(j + u * RPS, j1 - 1), 0);
+            kk[u] = *reinterpret_cast<const kvec*>(Kb + (size_t)jj * p.d);
+            vv[u] = *reinterpret_cast<const kvec*>(Vb + (size_t)jj * p.d);
         }
+    };
+    auto consume = [&](const kvec (&kk)[U], const kvec (&vv)[U], int j) {
+        float sc[U];
+        float bm = -1e30f;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float dot = 0.f;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) dot += qv[e] * (float)kv[u][e];
+            for (int e = 0; e < EPL; ++e) dot += qv[e] * (float)kk[u][e];
             dot = LPH == 16 ? group_sum16(dot) : group_sum8(dot);
-            const int jj = j + u * RPS;
-            if (active && jj < j1 && (c % LPH) == 0) s_scores[(jj - j0) * p.H + h] = dot * p.scale;
+            sc[u] = (active && j + u * RPS < j1) ? dot : -1e30f;
+            bm = fmaxf(bm, sc[u]);
         }
-    }
-    __syncthreads();
-    // per-head max / exp / sum over the chunk
-    const int nk = j1 - j0;
-    for (int hh = wid; hh < p.H; hh += nwaves) {
-        float mx = -1e10f;
-        for (int j = lane; j < nk; j += 64) mx = fmaxf(mx, s_scores[j * p.H + hh]);
-        mx = wave_max(mx);
-        float sum = 0.f;
-        for (int j = lane; j < nk; j += 64) {
-            float e = expf(s_scores[j * p.H + hh] - mx);
-            s_scores[j * p.H + hh] = e;
-            sum += e;
-        }
-        sum = wave_sum(sum);
-        if (lane == 0) {
-            s_m[hh] = mx;
-            s_l[hh] = sum;
-        }
-    }
-    __syncthreads();
-    // pass 2: weighted sum of V
-    float acc[EPL];
+        const float m_new = fmaxf(m_run, bm);
+        const float alpha = FAST ? __expf(m_run - m_new) : expf(m_run - m_new);
+        float ps = 0.f;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-    for (int j = j0 + rslot; j < j1; j += RPS * U) {
-        kvec vv[U];
+        for (int e = 0; e < EPL; ++e) acc[e] *= alpha;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int jj = min(j + u * RPS, j1 - 1);
-            vv[u] = *reinterpret_cast<const kvec*>(Vb + (size_t)jj * p.d);
+            const float pe = FAST ? __expf(sc[u] - m_new) : expf(sc[u] - m_new);
+            ps += pe;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] += pe * (float)vv[u][e];
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int jj = j + u * RPS;
-            const float pj = (active && jj < j1) ? s_scores[(jj - j0) * p.H + h] : 0.f;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) acc[e] += pj * (float)vv[u][e];
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+    };
+
+    {
+        kvec ka[U], va[U], kb[U], vb[U];
+        int j = j0 + rslot;
+        if (j0 < j1) {
+            load(ka, va, j);
+            while (true) {
+                const bool more1 = j + step < j1 + RPS;  // some row slot still has keys in the next iteration
+                if (more1) load(kb, vb, j + step);
+                consume(ka, va, j);
+                j += step;
+                if (!more1) break;
+                const bool more2 = j + step < j1 + RPS;
+                if (more2) load(ka, va, j + step);
+                consume(kb, vb, j);
+                j += step;
+                if (!more2) break;
+            }
         }
     }
+    // merge the RPS row slots (lanes of one LPH group carry identical m, l)
+    s_ml[threadIdx.x][0] = m_run;
+    s_ml[threadIdx.x][1] = l_run;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) s_red[threadIdx.x * EPL + e] = active ? acc[e] : 0.f;
+    for (int e = 0; e < EPL; ++e) s_red[threadIdx.x * EPL + e] = acc[e];
     __syncthreads();
     if (rslot == 0) {
+        float M = -1e10f;
+        for (int r = 0; r < RPS; ++r) M = fmaxf(M, s_ml[r * LPR + c][0]);
+        float L = 0.f, o[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+        for (int r = 0; r < RPS; ++r) {
+            const int t = r * LPR + c;
+            const float wgt = s_ml[t][1] > 0.f ? (FAST ? __expf(s_ml[t][0] - M) : expf(s_ml[t][0] - M)) : 0.f;
+            L += wgt * s_ml[t][1];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[e] += wgt * s_red[t * EPL + e];
+        }
         float* po = p.direct_out ? p.direct_out + (size_t)b * p.d + h * 64 + e0
                                  : p.part_o + ((size_t)b * p.nsplit + split) * p.d + h * 64 + e0;
-        const float norm = p.direct_out ? 1.0f / s_l[h] : 1.0f;
+        const float norm = p.direct_out ? 1.0f / L : 1.0f;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            float v = 0.f;
-            for (int r = 0; r < RPS; ++r) v += s_red[(r * LPR + c) * EPL + e];
-            po[e] = v * norm;
-        }
+        for (int e = 0; e < EPL; ++e) po[e] = o[e] * norm;
         if (!p.direct_out && (c % LPH) == 0) {
             float* pml = p.part_ml + (((size_t)b * p.nsplit + split) * p.H + h) * 2;
-            pml[0] = s_m[h];
-            pml[1] = s_l[h];
+            pml[0] = M;
+            pml[1] = L;
         }
     }
 }
 template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStream_t st) {
     constexpr int LPH = sizeof(TKV) == 4 ? 16 : 8;
+    constexpr bool FAST = sizeof(TKV) == 2;
     const int LPR = p.H * LPH;
     const int RPS = 256 / LPR;
-    // block rounded up to whole waves: the spare lanes take no rows (rslot >= RPS) but join the wave-wide reductions
-    hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH>), dim3(p.nsplit, p.B), dim3((RPS * LPR + 63) / 64 * 64), 0, st, p);
+    // block rounded up to whole waves: the spare lanes take no rows (rslot >= RPS) but stay in the DPP groups
+    hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST>), dim3(p.nsplit, p.B), dim3((RPS * LPR + 63) / 64 * 64), 0, st, p);
 }
 template void launch_attn_decode<float>(const AttnDecParams&, hipStream_t);
 template void launch_attn_decode<bf16>(const AttnDecParams&, hipStream_t);
