@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Developer experiment: per-kernel cost of 40-node graph chains of the small decode kernels (wm_bench_kernel ids 10-16)."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from whisper_mojo_amd import WhisperConfig, _lib, DT_BF16
+from whisper_mojo_amd.loader import WeightLoader
+from whisper_mojo_amd.whisper import Whisper
+L = _lib.lib()
+cfg = WhisperConfig.tiny()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+w = np.empty(cfg.weight_count(), np.float32)
+d = cfg.dims()
+L.wm_synth_weights(C.byref(d), 0, w.ctypes.data_as(C.POINTER(C.c_float)))
+m = Whisper(cfg, compute_dtype=DT_BF16, max_batch=B)
+m.load(WeightLoader.from_array(w))
+st = C.c_void_p()
+_lib.check(L.wm_state_new(m._h, B, C.byref(st)))
+mel = np.zeros((B, 80, 3000), np.float32)
+_lib.check(L.wm_encode(m._h, st, mel.ctypes.data_as(C.c_void_p), 0, B, None))
+names = {10: "embed x40", 11: "set_step x40", 12: "combine x40", 13: "dec_linear(no LN) x40", 14: "dec_linear(LN) x40",
+         15: "embed/combine/set_step mix", 16: "dec_linear(LN)/combine alternating"}
+for k, n in names.items():
+    us = C.c_float()
+    _lib.check(L.wm_bench_kernel(m._h, st, k, 50, C.byref(us)))
+    print(f"{n:40s} {us.value:6.2f} us/kernel")

@@ -7,6 +7,8 @@
 // position add (whisper.mojo:141-149); argmax (whisper_tensor.mojo:431-439).
 #include "wm_kernels.h"
 
+#include <cstdlib>
+
 namespace wm {
 
 // ------------------------------------------------------------------------------------------------------------
@@ -28,46 +30,34 @@ void launch_dec_embed(const float* tok_emb, const float* pos_emb, const int* tok
 // all B rows sharing the pass — the batched form of the reference's "parallel over n, dot over K" GEMV
 // (whisper_tensor.mojo:158-175).
 //
-// These launches move 0.3-1.2 MB each (80 MB for the logits): they are LATENCY bound, so the kernel is shaped so that
-// every global load a wave needs is in flight at once — one dependent HBM round trip per launch:
-//   * workgroup = 16 output columns x NRB row blocks of 16 utterances; its 4 waves split K (wave w owns k-steps
-//     4j+w), so a wave's whole operand set is CH weight fragments + NRB*CH activation fragments, all register resident
-//     (CH = K/128 when that fits, else the K loop runs in chunks of CH k-steps);
-//   * K = d_model launches (CH <= 4) take all 4 row blocks per workgroup (weights fetched once); K = ffn launches take
-//     one row block per workgroup (grid.y = 4; the 3 re-reads of the weight tile hit L2);
-//   * LayerNorm prologue: row statistics (one-pass variance, as the reference) come from the SAME activation
-//     fragments — lane partials, a 4-lane DPP-free butterfly, and one LDS exchange between the 4 K-split waves — so
-//     the normalised vector never exists in memory and nothing is loaded twice;
-//   * computed as outᵀ (A-operand = weight fragment): a lane owns 4 consecutive columns of one utterance; the 4
-//     K-partials meet in LDS, then bias / GELU / residual / KV-cache scatter.
-template <typename TW, int CH, int NRB>
-__global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
-    __shared__ float s_stat[4][NRB][16][2];
-    __shared__ __attribute__((aligned(16))) f32x4 s_red[4][NRB][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+// These launches move 0.3-1.2 MB: they are LATENCY bound, and what they wait for is (a) one memory round trip and
+// (b) the serial instruction stream of a wave (a lone wave retires ~1 instruction per 4-5 cycles: 1 700 instructions
+// = 4 us, measured).  So the kernel minimises the per-wave stream:
+//   * workgroup = one 16x16 output tile (16 utterances x 16 columns); its NW <= 16 waves split K, wave w owning
+//     k-steps w, w+NW, … (KPW = 1 for K = d_model): a wave's whole job is KPW weight fragments, KPW activation
+//     fragments and KPW MFMAs, everything requested up front;
+//   * LayerNorm prologue: row statistics (one-pass variance, as the reference) from the SAME activation registers —
+//     8·KPW values per lane, a 4-lane butterfly, one LDS exchange between the NW waves;
+//   * computed as outᵀ (A-operand = weight fragment): a lane owns 4 consecutive columns of one utterance; the NW
+//     K-partials meet in LDS and wave 0 finishes (bias / GELU / residual / KV-cache append), with its epilogue operands
+//     requested before anything else so they ride the same round trip.
+template <typename TW, int KPW, bool LN>
+__global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
+    __shared__ float s_stat[16][16][2];
+    __shared__ __attribute__((aligned(16))) f32x4 s_red[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    const int rb0 = blockIdx.y * NRB;
+    const int n0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
     int wrow = n0 + r16;
     wrow = wrow < p.N ? wrow : p.N - 1;
+    int xrow = b0 + r16;
+    xrow = xrow < p.B ? xrow : p.B - 1;
     const TW* wp = (const TW*)p.W + (size_t)wrow * p.K + g * 8;
-    const int nch = (p.K >> 7) / CH;  // chunks of CH k-steps per wave
-    const float* xrow[NRB];
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) {
-        int row = (rb0 + rb) * 16 + r16;
-        row = row < p.B ? row : p.B - 1;
-        xrow[rb] = p.x + (size_t)row * p.ldx + g * 8;
-    }
-    f32x4 acc[NRB];
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xp = p.x + (size_t)xrow * p.ldx + g * 8;
 
-    // Epilogue operands are requested FIRST so they ride the same memory round trip as the weights: each later
-    // dependent global load would add ~1 us to a ~5 us launch.
-    const int eb = (rb0 + (w < NRB ? w : 0)) * 16 + r16;  // utterance / column quad this lane finishes
-    const int en = n0 + g * 4;
-    const bool epi = w < NRB && eb < p.B;
+    // epilogue operands (wave 0)
+    const int eb = b0 + r16, en = n0 + g * 4;
+    const bool epi = w == 0 && eb < p.B;
     float bias4[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 res4 = f32x4{0.f, 0.f, 0.f, 0.f};
     int cache_row = 0;
@@ -79,112 +69,76 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
         if (p.residual) res4 = *reinterpret_cast<const f32x4*>(p.residual + (size_t)eb * p.ldr + en);
         if (p.kcache) cache_row = p.ctl->len;
     }
-    constexpr bool EARLY_GB = sizeof(TW) == 2 || CH <= 3;  // keep LN gamma/beta in registers when they fit
-
-    for (int c = 0; c < nch; ++c) {
-        Frag<TW> wf[CH];
-        f32x4 xa[NRB][CH][2];
-        f32x4 gb[EARLY_GB ? CH : 1][4];
+    Frag<TW> wf[KPW];
+    f32x4 xa[KPW][2], gb[LN ? KPW : 1][4];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) wf[i] = load_frag<TW>(wp + ((c * CH + i) * 4 + w) * 32);
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const float* xp = xrow[rb] + ((c * CH + i) * 4 + w) * 32;
-                xa[rb][i][0] = *reinterpret_cast<const f32x4*>(xp);
-                xa[rb][i][1] = *reinterpret_cast<const f32x4*>(xp + 4);
-            }
-        if (EARLY_GB && p.ln_g) {
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const int k = ((c * CH + i) * 4 + w) * 32 + g * 8;
-                gb[i][0] = *reinterpret_cast<const f32x4*>(p.ln_g + k);
-                gb[i][1] = *reinterpret_cast<const f32x4*>(p.ln_g + k + 4);
-                gb[i][2] = *reinterpret_cast<const f32x4*>(p.ln_b + k);
-                gb[i][3] = *reinterpret_cast<const f32x4*>(p.ln_b + k + 4);
-            }
-        }
-        float mean[NRB], rstd[NRB];
-        if (p.ln_g) {  // host guarantees nch == 1 here: the fragments cover the whole row
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) {
-                float sm = 0.f, sq = 0.f;
-#pragma unroll
-                for (int i = 0; i < CH; ++i)
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float v = xa[rb][i][h2][j];
-                            sm += v;
-                            sq += v * v;
-                        }
-                sm += __shfl_xor(sm, 16, 64);
-                sq += __shfl_xor(sq, 16, 64);
-                sm += __shfl_xor(sm, 32, 64);
-                sq += __shfl_xor(sq, 32, 64);
-                if (g == 0) {
-                    s_stat[w][rb][r16][0] = sm;
-                    s_stat[w][rb][r16][1] = sq;
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) {
-                const float sm = s_stat[0][rb][r16][0] + s_stat[1][rb][r16][0] + s_stat[2][rb][r16][0] + s_stat[3][rb][r16][0];
-                const float sq = s_stat[0][rb][r16][1] + s_stat[1][rb][r16][1] + s_stat[2][rb][r16][1] + s_stat[3][rb][r16][1];
-                mean[rb] = sm / (float)p.K;
-                const float var = (sq / (float)p.K) - (mean[rb] * mean[rb]);
-                rstd[rb] = 1.0f / sqrtf(var + 1e-5f);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            float gam[8], bet[8];
-            if (p.ln_g) {
-                f32x4 g0, g1, b0, b1;
-                if (EARLY_GB) {
-                    g0 = gb[i][0];
-                    g1 = gb[i][1];
-                    b0 = gb[i][2];
-                    b1 = gb[i][3];
-                } else {
-                    const int k = ((c * CH + i) * 4 + w) * 32 + g * 8;
-                    g0 = *reinterpret_cast<const f32x4*>(p.ln_g + k);
-                    g1 = *reinterpret_cast<const f32x4*>(p.ln_g + k + 4);
-                    b0 = *reinterpret_cast<const f32x4*>(p.ln_b + k);
-                    b1 = *reinterpret_cast<const f32x4*>(p.ln_b + k + 4);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    gam[j] = g0[j];
-                    gam[4 + j] = g1[j];
-                    bet[j] = b0[j];
-                    bet[4 + j] = b1[j];
-                }
-            }
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) {
-                float xv[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    xv[j] = xa[rb][i][0][j];
-                    xv[4 + j] = xa[rb][i][1][j];
-                }
-                if (p.ln_g) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) xv[j] = (xv[j] - mean[rb]) * rstd[rb] * gam[j] + bet[j];
-                }
-                acc[rb] = mma32(wf[i], make_frag<TW>(xv), acc[rb]);
-            }
+    for (int i = 0; i < KPW; ++i) {
+        const int k = (w + nw * i) * 32;
+        wf[i] = load_frag<TW>(wp + k);
+        xa[i][0] = *reinterpret_cast<const f32x4*>(xp + k);
+        xa[i][1] = *reinterpret_cast<const f32x4*>(xp + k + 4);
+        if (LN) {
+            gb[i][0] = *reinterpret_cast<const f32x4*>(p.ln_g + k + g * 8);
+            gb[i][1] = *reinterpret_cast<const f32x4*>(p.ln_g + k + g * 8 + 4);
+            gb[i][2] = *reinterpret_cast<const f32x4*>(p.ln_b + k + g * 8);
+            gb[i][3] = *reinterpret_cast<const f32x4*>(p.ln_b + k + g * 8 + 4);
         }
     }
+    float mean = 0.f, rstd = 1.f;
+    if (LN) {
+        float sm = 0.f, sq = 0.f;
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) s_red[w][rb][lane] = acc[rb];
+        for (int i = 0; i < KPW; ++i)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = xa[i][h2][j];
+                    sm += v;
+                    sq += v * v;
+                }
+        sm += __shfl_xor(sm, 16, 64);
+        sq += __shfl_xor(sq, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        if (g == 0) {
+            s_stat[w][r16][0] = sm;
+            s_stat[w][r16][1] = sq;
+        }
+        __syncthreads();
+        sm = 0.f;
+        sq = 0.f;
+        for (int k = 0; k < nw; ++k) {
+            sm += s_stat[k][r16][0];
+            sq += s_stat[k][r16][1];
+        }
+        mean = sm / (float)p.K;
+        const float var = (sq / (float)p.K) - (mean * mean);
+        rstd = 1.0f / sqrtf(var + 1e-5f);
+    }
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        float xv[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xv[j] = xa[i][0][j];
+            xv[4 + j] = xa[i][1][j];
+        }
+        if (LN) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xv[j] = (xv[j] - mean) * rstd * gb[i][0][j] + gb[i][2][j];
+                xv[4 + j] = (xv[4 + j] - mean) * rstd * gb[i][1][j] + gb[i][3][j];
+            }
+        }
+        acc = mma32(wf[i], make_frag<TW>(xv), acc);
+    }
+    s_red[w][lane] = acc;
     __syncthreads();
     if (epi) {
-        f32x4 v = s_red[0][w][lane] + s_red[1][w][lane] + s_red[2][w][lane] + s_red[3][w][lane];
+        f32x4 v = s_red[0][lane];
+        for (int k = 1; k < nw; ++k) v += s_red[k][lane];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += bias4[r];
         if (p.act) {
@@ -211,27 +165,28 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
         }
     }
 }
-template <typename TW, int CH, int NRB> static void launch_dec_linear_t(const DecLinearParams& p, hipStream_t st) {
-    const int nrb = (p.B + 15) / 16;
-    hipLaunchKernelGGL((dec_linear_kernel<TW, CH, NRB>), dim3((p.N + 15) / 16, (nrb + NRB - 1) / NRB), dim3(256), 0, st, p);
+template <typename TW, int KPW> static void launch_dec_linear_t(const DecLinearParams& p, int nw, hipStream_t st) {
+    const dim3 grid((p.N + 15) / 16, (p.B + 15) / 16), block(nw * 64);
+    if (p.ln_g)
+        hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, true>), grid, block, 0, st, p);
+    else
+        hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, false>), grid, block, 0, st, p);
 }
-// K % 128 == 0.  kpw = k-steps per wave = K/128.
+// K % 32 == 0 and (K/32) must factor as NW * KPW with NW <= 16, KPW <= 4 (true for every K = 128·j, j <= 16)
 template <typename TW> void launch_dec_linear(const DecLinearParams& p, hipStream_t st) {
-    const int kpw = p.K >> 7;
-    constexpr bool W32 = sizeof(TW) == 4;
-    switch (kpw) {
-        case 1: return launch_dec_linear_t<TW, 1, 4>(p, st);
-        case 2: return launch_dec_linear_t<TW, 2, 4>(p, st);
-        case 3: return launch_dec_linear_t<TW, 3, 4>(p, st);
-        case 4: return launch_dec_linear_t<TW, 4, 4>(p, st);
-        default: break;
+    const int ksteps = p.K >> 5;
+    int nw = 1;
+    for (int c = 16; c >= 1; --c)
+        if (ksteps % c == 0 && ksteps / c <= 4) {
+            nw = c;
+            break;
+        }
+    switch (ksteps / nw) {
+        case 1: return launch_dec_linear_t<TW, 1>(p, nw, st);
+        case 2: return launch_dec_linear_t<TW, 2>(p, nw, st);
+        case 3: return launch_dec_linear_t<TW, 3>(p, nw, st);
+        default: return launch_dec_linear_t<TW, 4>(p, nw, st);
     }
-    if (!W32 && kpw % 12 == 0) return launch_dec_linear_t<TW, 12, 1>(p, st);
-    if (kpw % 8 == 0) return launch_dec_linear_t<TW, 8, 1>(p, st);
-    if (kpw % 6 == 0) return launch_dec_linear_t<TW, 6, 1>(p, st);
-    if (kpw % 4 == 0) return launch_dec_linear_t<TW, 4, 1>(p, st);
-    if (kpw % 3 == 0) return launch_dec_linear_t<TW, 3, 1>(p, st);
-    return launch_dec_linear_t<TW, 1, 1>(p, st);
 }
 template void launch_dec_linear<float>(const DecLinearParams&, hipStream_t);
 template void launch_dec_linear<bf16>(const DecLinearParams&, hipStream_t);
@@ -378,7 +333,7 @@ template void launch_dec_logits<f16>(const DecLinearParams&, hipStream_t);
 // attn_combine, or the normalised output directly when the chunk is the whole sequence.
 // Scale after the dot product and max initialised to -1e10 follow layers.mojo:196,212 (the mask branch at :213 is a
 // no-op for j <= len-1 and is omitted).
-template <typename TKV, int LPH, bool FAST>
+template <typename TKV, int LPH, bool FAST, bool NT>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecParams p) {
     constexpr int EPL = 64 / LPH;  // elements per lane
     constexpr int U = 4;
@@ -412,8 +367,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecParams p) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int jj = max(min(j + u * RPS, j1 - 1), 0);
-            kk[u] = *reinterpret_cast<const kvec*>(Kb + (size_t)jj * p.d);
-            vv[u] = *reinterpret_cast<const kvec*>(Vb + (size_t)jj * p.d);
+            if (NT) {  // read-once stream: keep it out of L2 / Infinity Cache so the weights stay resident there
+                kk[u] = __builtin_nontemporal_load(reinterpret_cast<const kvec*>(Kb + (size_t)jj * p.d));
+                vv[u] = __builtin_nontemporal_load(reinterpret_cast<const kvec*>(Vb + (size_t)jj * p.d));
+            } else {
+                kk[u] = *reinterpret_cast<const kvec*>(Kb + (size_t)jj * p.d);
+                vv[u] = *reinterpret_cast<const kvec*>(Vb + (size_t)jj * p.d);
+            }
         }
     };
     auto consume = [&](const kvec (&kk)[U], const kvec (&vv)[U], int j) {
@@ -500,7 +460,12 @@ template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStrea
     const int LPR = p.H * LPH;
     const int RPS = 256 / LPR;
     // block rounded up to whole waves: the spare lanes take no rows (rslot >= RPS) but stay in the DPP groups
-    hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST>), dim3(p.nsplit, p.B), dim3((RPS * LPR + 63) / 64 * 64), 0, st, p);
+    const dim3 grid(p.nsplit, p.B), block((RPS * LPR + 63) / 64 * 64);
+    static const bool nt_off = getenv("WM_NO_NT") != nullptr;
+    if (p.n_keys >= 0 && !nt_off)  // the cross-attention K/V stream (1500 rows per utterance, read once per step)
+        hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true>), grid, block, 0, st, p);
+    else
+        hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, false>), grid, block, 0, st, p);
 }
 template void launch_attn_decode<float>(const AttnDecParams&, hipStream_t);
 template void launch_attn_decode<bf16>(const AttnDecParams&, hipStream_t);

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -129,8 +130,21 @@ struct wm_state {
     int out_stride = 0;
     bool has_enc = false, has_cross = false;
     int host_len = 0;
-    hipGraphExec_t step_graph = nullptr;  // captured [decode step + argmax + advance]; replayed once per token
+    // Decode lanes: the batch is cut into independent sub-batches, each decoding on its own HIP stream with its own
+    // control block and captured step graph, so one lane's latency-bound launches overlap another's K/V streaming.
+    struct Lane {
+        int b0 = 0, nb = 0;
+        hipStream_t st = nullptr;
+        StepCtl* ctl = nullptr;
+        static const int NEXEC = 3;  // instances of the same captured step, launched round-robin
+        hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};
+        hipEvent_t done = nullptr;
+    };
+    std::vector<Lane> lanes;
+    hipEvent_t enc_done = nullptr;
+    StepCtl* h_ctl = nullptr;  // pinned host copy of the control blocks (finish polling)
     int graph_eot = 0, graph_ignore = 0;
+    bool graphs_valid = false;
     const float* last_mel = nullptr;  // device pointer of the last encoded batch (bench replays the encoder on it)
     // encoder arena (sized for Bc utterances)
     DevBuf mel_dev, mel_t, h1, x, xn, qkv, ao, hid, enc_t;
@@ -393,7 +407,14 @@ extern "C" int wm_model_load(const char* path, const wm_config* cfg, int device,
 extern "C" void wm_state_free(wm_state* s) {
     if (!s) return;
     (void)hipSetDevice(s->m->device);
-    if (s->step_graph) (void)hipGraphExecDestroy(s->step_graph);
+    for (auto& ln : s->lanes) {
+        for (auto& g : ln.graph)
+            if (g) (void)hipGraphExecDestroy(g);
+        if (ln.st) (void)hipStreamDestroy(ln.st);
+        if (ln.done) (void)hipEventDestroy(ln.done);
+    }
+    if (s->enc_done) (void)hipEventDestroy(s->enc_done);
+    if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     DevBuf* bs[] = {&s->mel_dev, &s->mel_t, &s->h1, &s->x, &s->xn, &s->qkv, &s->ao, &s->hid, &s->enc_t, &s->enc_f,
                     &s->cross_kv, &s->self_kv, &s->dx, &s->dq, &s->dattn, &s->dhid, &s->part_o, &s->part_ml, &s->logits,
                     &s->tok, &s->pos, &s->ctl, &s->out_tokens, &s->n_tokens, &s->finished};
@@ -446,7 +467,7 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
     A(s->logits, (size_t)B * m->Vpad * 4);
     A(s->tok, (size_t)B * 4, true);
     A(s->pos, (size_t)B * 4, true);
-    A(s->ctl, sizeof(StepCtl), true);
+    A(s->ctl, sizeof(StepCtl) * 8, true);  // [0] whole-batch control (wm_decode_step), [1..] one per decode lane
     A(s->out_tokens, (size_t)B * s->out_stride * 4, true);
     A(s->n_tokens, (size_t)B * 4, true);
     A(s->finished, (size_t)B * 4, true);
@@ -456,6 +477,38 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
         g_err = keep;
         return rc;
     }
+    {  // decode lanes
+        int nl = B >= 32 ? 2 : 1;
+        if (const char* e = getenv("WM_DEC_LANES")) nl = std::max(1, std::min(4, atoi(e)));
+        nl = std::min(nl, (B + 15) / 16);
+        s->lanes.resize(nl);
+        const int per = ((B + nl - 1) / nl + 15) / 16 * 16;  // whole MFMA row blocks per lane
+        int b0 = 0;
+        for (int i = 0; i < nl; ++i) {
+            wm_state::Lane& ln = s->lanes[i];
+            ln.b0 = b0;
+            ln.nb = std::max(0, std::min(per, B - b0));
+            b0 += ln.nb;
+            ln.ctl = s->ctl.as<StepCtl>() + 1 + i;
+            hipError_t e = hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.done, hipEventDisableTiming);
+            if (e != hipSuccess) {
+                wm_state_free(s);
+                return fail(WM_E_HIP, "lane stream: %s", hipGetErrorString(e));
+            }
+        }
+        while (!s->lanes.empty() && s->lanes.back().nb == 0) {
+            (void)hipStreamDestroy(s->lanes.back().st);
+            (void)hipEventDestroy(s->lanes.back().done);
+            s->lanes.pop_back();
+        }
+        hipError_t e = hipEventCreateWithFlags(&s->enc_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_ctl, sizeof(StepCtl) * 8, 0);
+        if (e != hipSuccess) {
+            wm_state_free(s);
+            return fail(WM_E_HIP, "event: %s", hipGetErrorString(e));
+        }
+    }
     *out = s;
     return 0;
 }
@@ -464,7 +517,7 @@ extern "C" int wm_state_reset(wm_state* s) {
     if (!s) return fail(WM_E_ARG, "null state");
     HIPCHK(hipSetDevice(s->m->device));
     hipStream_t st = s->m->stream;
-    HIPCHK(hipMemsetAsync(s->ctl.p, 0, sizeof(StepCtl), st));
+    HIPCHK(hipMemsetAsync(s->ctl.p, 0, s->ctl.bytes, st));
     HIPCHK(hipMemsetAsync(s->n_tokens.p, 0, s->n_tokens.bytes, st));
     HIPCHK(hipMemsetAsync(s->finished.p, 0, s->finished.bytes, st));
     s->has_enc = s->has_cross = false;
@@ -664,44 +717,59 @@ static void attn_decode_dispatch(int dt, const AttnDecParams& p, hipStream_t st)
     DISPATCH_DT(dt, TT, launch_attn_decode<TT>(p, st));
 }
 
-static void launch_cross_attn(wm_model* m, wm_state* s, int l) {
+// A view of `nb` utterances starting at b0, decoding on stream st under control block ctl.
+struct DecView {
+    int b0, nb;
+    hipStream_t st;
+    StepCtl* ctl;
+};
+static DecView whole_batch(wm_model* m, wm_state* s) { return DecView{0, s->B, m->stream, s->ctl.as<StepCtl>()}; }
+
+static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v) {
     const wm_dims& c = m->cfg.dims;
     const size_t d = c.d_model, ks = dt_size(m->cfg.kv_dtype);
     const size_t cross_l = (size_t)s->B * c.n_audio_ctx * d;
+    const size_t boff = (size_t)v.b0 * c.n_audio_ctx * d;
     AttnDecParams a{};
-    a.q = s->dq.as<float>();
-    a.K = off_bytes(s->cross_kv, (size_t)(2 * l) * cross_l * ks);
-    a.V = off_bytes(s->cross_kv, (size_t)(2 * l + 1) * cross_l * ks);
+    a.q = s->dq.as<float>() + (size_t)v.b0 * d;
+    a.K = off_bytes(s->cross_kv, ((size_t)(2 * l) * cross_l + boff) * ks);
+    a.V = off_bytes(s->cross_kv, ((size_t)(2 * l + 1) * cross_l + boff) * ks);
     a.batch_stride = (long)((size_t)c.n_audio_ctx * d);
     a.n_keys = c.n_audio_ctx;
-    a.ctl = s->ctl.as<StepCtl>();
+    if (const char* e = getenv("WM_DEBUG_NKEYS")) a.n_keys = atoi(e);  // experiments only: wrong results
+    a.ctl = v.ctl;
     a.nsplit = s->nsplit;
     a.scale = 1.0f / sqrtf(64.0f);
-    a.part_o = s->part_o.as<float>();
-    a.part_ml = s->part_ml.as<float>();
+    a.part_o = s->part_o.as<float>() + (size_t)v.b0 * s->nsplit * d;
+    a.part_ml = s->part_ml.as<float>() + (size_t)v.b0 * s->nsplit * c.n_heads * 2;
     a.H = c.n_heads;
     a.d = c.d_model;
-    a.B = s->B;
-    attn_decode_dispatch(m->cfg.kv_dtype, a, m->stream);
+    a.B = v.nb;
+    attn_decode_dispatch(m->cfg.kv_dtype, a, v.st);
 }
 
-static void decode_core(wm_model* m, wm_state* s, bool want_logits) {
+static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_logits) {
     const wm_dims& c = m->cfg.dims;
     const int T = m->cfg.compute_dtype, KV = m->cfg.kv_dtype;
-    const int B = s->B;
+    const int B = v.nb;
     const size_t d = c.d_model, ks = dt_size(KV);
-    hipStream_t st = m->stream;
-    const StepCtl* ctl = s->ctl.as<StepCtl>();
+    hipStream_t st = v.st;
+    const StepCtl* ctl = v.ctl;
     const float scale = 1.0f / sqrtf(64.0f);
-    const size_t self_l = (size_t)B * c.n_text_ctx * d;  // elements per (layer, K|V)
-    launch_dec_embed(m->tok_emb_f.as<float>(), m->dec_pos.as<float>(), s->tok.as<int>(), s->pos.as<int>(), s->dx.as<float>(), B, c.d_model, st);
+    const size_t self_l = (size_t)s->B * c.n_text_ctx * d;  // elements per (layer, K|V)
+    const size_t self_b = (size_t)v.b0 * c.n_text_ctx * d;
+    float* dx = s->dx.as<float>() + (size_t)v.b0 * d;
+    float* dq = s->dq.as<float>() + (size_t)v.b0 * d;
+    float* dattn = s->dattn.as<float>() + (size_t)v.b0 * d;
+    float* dhid = s->dhid.as<float>() + (size_t)v.b0 * c.ffn;
+    launch_dec_embed(m->tok_emb_f.as<float>(), m->dec_pos.as<float>(), s->tok.as<int>() + v.b0, s->pos.as<int>() + v.b0, dx, B, c.d_model, st);
     for (int l = 0; l < c.n_layers; ++l) {
         DecLayer& w = m->dec[l];
-        void* sk = off_bytes(s->self_kv, (size_t)(2 * l) * self_l * ks);
-        void* sv = off_bytes(s->self_kv, (size_t)(2 * l + 1) * self_l * ks);
+        void* sk = off_bytes(s->self_kv, ((size_t)(2 * l) * self_l + self_b) * ks);
+        void* sv = off_bytes(s->self_kv, ((size_t)(2 * l + 1) * self_l + self_b) * ks);
         {  // LN1 -> q | k,v appended to the cache at row current_len   (layers.mojo:118-147)
             DecLinearParams p{};
-            p.x = s->dx.as<float>();
+            p.x = dx;
             p.ldx = c.d_model;
             p.ln_g = w.ln1_g.as<float>();
             p.ln_b = w.ln1_b.as<float>();
@@ -710,7 +778,7 @@ static void decode_core(wm_model* m, wm_state* s, bool want_logits) {
             p.K = c.d_model;
             p.B = B;
             p.bias = w.sqkv_b.as<float>();
-            p.out = s->dq.as<float>();
+            p.out = dq;
             p.ldo = c.d_model;
             p.kcache = sk;
             p.vcache = sv;
@@ -722,7 +790,7 @@ static void decode_core(wm_model* m, wm_state* s, bool want_logits) {
         }
         {  // self-attention over current_len+1 cached rows   (layers.mojo:186-272)
             AttnDecParams a{};
-            a.q = s->dq.as<float>();
+            a.q = dq;
             a.K = sk;
             a.V = sv;
             a.batch_stride = (long)((size_t)c.n_text_ctx * d);
@@ -730,7 +798,7 @@ static void decode_core(wm_model* m, wm_state* s, bool want_logits) {
             a.ctl = ctl;
             a.nsplit = 1;
             a.scale = scale;
-            a.direct_out = s->dattn.as<float>();
+            a.direct_out = dattn;
             a.H = c.n_heads;
             a.d = c.d_model;
             a.B = B;
@@ -745,16 +813,16 @@ static void decode_core(wm_model* m, wm_state* s, bool want_logits) {
             p.K = K;
             p.B = B;
             p.bias = bias.as<float>();
-            p.residual = s->dx.as<float>();
+            p.residual = dx;
             p.ldr = c.d_model;
-            p.out = s->dx.as<float>();
+            p.out = dx;
             p.ldo = c.d_model;
             dec_linear_dispatch(T, p, st);
         };
-        proj_residual(s->dattn.as<float>(), c.d_model, w.so_w, w.so_b);
+        proj_residual(dattn, c.d_model, w.so_w, w.so_b);
         {  // LNx -> cross q
             DecLinearParams p{};
-            p.x = s->dx.as<float>();
+            p.x = dx;
             p.ldx = c.d_model;
             p.ln_g = w.lnx_g.as<float>();
             p.ln_b = w.lnx_b.as<float>();
@@ -763,16 +831,17 @@ static void decode_core(wm_model* m, wm_state* s, bool want_logits) {
             p.K = c.d_model;
             p.B = B;
             p.bias = w.cq_b.as<float>();
-            p.out = s->dq.as<float>();
+            p.out = dq;
             p.ldo = c.d_model;
             dec_linear_dispatch(T, p, st);
         }
-        launch_cross_attn(m, s, l);
-        launch_attn_combine(s->part_o.as<float>(), s->part_ml.as<float>(), s->dattn.as<float>(), B, s->nsplit, c.n_heads, c.d_model, st);
-        proj_residual(s->dattn.as<float>(), c.d_model, w.co_w, w.co_b);
+        launch_cross_attn(m, s, l, v);
+        launch_attn_combine(s->part_o.as<float>() + (size_t)v.b0 * s->nsplit * d, s->part_ml.as<float>() + (size_t)v.b0 * s->nsplit * c.n_heads * 2,
+                            dattn, B, s->nsplit, c.n_heads, c.d_model, st);
+        proj_residual(dattn, c.d_model, w.co_w, w.co_b);
         {  // LN2 -> fc1 + GELU
             DecLinearParams p{};
-            p.x = s->dx.as<float>();
+            p.x = dx;
             p.ldx = c.d_model;
             p.ln_g = w.ln2_g.as<float>();
             p.ln_b = w.ln2_b.as<float>();
@@ -783,15 +852,15 @@ static void decode_core(wm_model* m, wm_state* s, bool want_logits) {
             p.bias = w.fc1_b.as<float>();
             p.act = 1;
             p.gelu_mode = m->cfg.gelu_mode;
-            p.out = s->dhid.as<float>();
+            p.out = dhid;
             p.ldo = c.ffn;
             dec_linear_dispatch(T, p, st);
         }
-        proj_residual(s->dhid.as<float>(), c.ffn, w.fc2_w, w.fc2_b);
+        proj_residual(dhid, c.ffn, w.fc2_w, w.fc2_b);
     }
     if (want_logits) {  // final LN + tied-embedding logits (whisper.mojo:156-166), no bias
         DecLinearParams p{};
-        p.x = s->dx.as<float>();
+        p.x = dx;
         p.ldx = c.d_model;
         p.ln_g = m->dec_ln_g.as<float>();
         p.ln_b = m->dec_ln_b.as<float>();
@@ -799,28 +868,29 @@ static void decode_core(wm_model* m, wm_state* s, bool want_logits) {
         p.N = c.vocab;
         p.K = c.d_model;
         p.B = B;
-        p.out = s->logits.as<float>();
+        p.out = s->logits.as<float>() + (size_t)v.b0 * m->Vpad;
         p.ldo = m->Vpad;
         DISPATCH_DT(T, TT, launch_dec_logits<TT>(p, st));
     }
 }
 
-static ArgmaxParams argmax_params(wm_model* m, wm_state* s, bool record, int eot, int ignore_eot, bool advance = false) {
+static ArgmaxParams argmax_params(wm_model* m, wm_state* s, const DecView& v, bool record, int eot, int ignore_eot,
+                                  bool advance = false) {
     ArgmaxParams a{};
-    a.logits = s->logits.as<float>();
+    a.logits = s->logits.as<float>() + (size_t)v.b0 * m->Vpad;
     a.ldl = m->Vpad;
     a.V = m->cfg.dims.vocab;
-    a.B = s->B;
-    a.next = s->tok.as<int>();
-    a.out_tokens = record ? s->out_tokens.as<int>() : nullptr;
+    a.B = v.nb;
+    a.next = s->tok.as<int>() + v.b0;
+    a.out_tokens = record ? s->out_tokens.as<int>() + (size_t)v.b0 * s->out_stride : nullptr;
     a.out_stride = s->out_stride;
-    a.n_tokens = s->n_tokens.as<int>();
-    a.finished = s->finished.as<int>();
-    a.ctl = s->ctl.as<StepCtl>();
+    a.n_tokens = s->n_tokens.as<int>() + v.b0;
+    a.finished = s->finished.as<int>() + v.b0;
+    a.ctl = v.ctl;
     a.eot = eot;
     a.ignore_eot = ignore_eot;
     a.advance = advance ? 1 : 0;
-    a.pos = s->pos.as<int>();
+    a.pos = s->pos.as<int>() + v.b0;
     return a;
 }
 
@@ -839,6 +909,7 @@ extern "C" int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, i
     }
     HIPCHK(hipSetDevice(m->device));
     hipStream_t st = m->stream;
+    const DecView v = whole_batch(m, s);
     std::vector<int32_t> col(B), pos(B);
     for (int i = 0; i < q_len; ++i) {
         for (int b = 0; b < B; ++b) {
@@ -847,14 +918,14 @@ extern "C" int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, i
         }
         HIPCHK(hipMemcpyAsync(s->tok.p, col.data(), B * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(s->pos.p, pos.data(), B * 4, hipMemcpyHostToDevice, st));
-        launch_set_step(s->ctl.as<StepCtl>(), s->host_len, 1, nullptr, 0, nullptr, 0, B, st);
-        decode_core(m, s, i == q_len - 1);
+        launch_set_step(v.ctl, s->host_len, 1, nullptr, 0, nullptr, 0, B, st);
+        decode_core(m, s, v, i == q_len - 1);
         HIPCHK(hipStreamSynchronize(st));  // col/pos are reused next iteration
         s->host_len += 1;
     }
-    launch_set_step(s->ctl.as<StepCtl>(), s->host_len, 1, nullptr, 0, nullptr, 0, B, st);
+    launch_set_step(v.ctl, s->host_len, 1, nullptr, 0, nullptr, 0, B, st);
     if (next) {
-        launch_argmax_step(argmax_params(m, s, false, -1, 1), st);
+        launch_argmax_step(argmax_params(m, s, v, false, -1, 1), st);
         HIPCHK(hipMemcpyAsync(next, s->tok.p, B * 4, hipMemcpyDeviceToHost, st));
     }
     if (logits)
@@ -867,69 +938,99 @@ extern "C" int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, i
 // ---- Whisper.transcribe: whisper.mojo:184-223 ------------------------------------------------------------------------
 static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o) {
     const int B = s->B;
-    hipStream_t st = m->stream;
-    StepCtl* ctl = s->ctl.as<StepCtl>();
+    hipStream_t st0 = m->stream;
     // tokens = prompt (whisper.mojo:187-191, 200-202)
     std::vector<int32_t> rows((size_t)B * s->out_stride, 0), nt(B, o->n_prompt);
     for (int b = 0; b < B; ++b)
         for (int i = 0; i < o->n_prompt; ++i) rows[(size_t)b * s->out_stride + i] = o->prompt[i];
-    HIPCHK(hipMemcpyAsync(s->out_tokens.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(s->n_tokens.p, nt.data(), B * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(s->finished.p, 0, B * 4, st));
-    HIPCHK(hipMemsetAsync(s->ctl.p, 0, sizeof(StepCtl), st));
-    HIPCHK(hipStreamSynchronize(st));  // rows / nt are pageable host memory
-    // prefill (whisper.mojo:195, start_pos=0): the q_len = n_prompt causal block equals n_prompt single-token steps
-    for (int i = 0; i < o->n_prompt; ++i) {
-        launch_set_step(ctl, i, 1, s->pos.as<int>(), i, s->tok.as<int>(), o->prompt[i], B, st);
-        decode_core(m, s, i == o->n_prompt - 1);
-    }
-    launch_argmax_step(argmax_params(m, s, true, o->eot, o->ignore_eot), st);  // :198-203
-    // incremental steps: start_pos = current_len - 1 (reference, :217) or current_len (HF)
-    const int first_pos = o->pos_mode == WM_POS_REF ? o->n_prompt - 1 : o->n_prompt;
-    launch_set_step(ctl, o->n_prompt, 1, s->pos.as<int>(), first_pos, nullptr, 0, B, st);
-    // steady state: one captured graph = [39 decode-step launches + argmax/bookkeeping]; every per-step quantity
-    // (token, position, cache length) lives in HBM, so the same graph is replayed for every token
+    HIPCHK(hipMemcpyAsync(s->out_tokens.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st0));
+    HIPCHK(hipMemcpyAsync(s->n_tokens.p, nt.data(), B * 4, hipMemcpyHostToDevice, st0));
+    HIPCHK(hipMemsetAsync(s->finished.p, 0, B * 4, st0));
+    HIPCHK(hipMemsetAsync(s->ctl.p, 0, s->ctl.bytes, st0));
+    HIPCHK(hipStreamSynchronize(st0));  // rows / nt are pageable host memory; also: encoder + cross K/V complete
+
     static const bool no_graph = getenv("WM_NO_GRAPH") != nullptr;
-    if (!no_graph && (!s->step_graph || s->graph_eot != o->eot || s->graph_ignore != o->ignore_eot)) {
-        if (s->step_graph) (void)hipGraphExecDestroy(s->step_graph);
-        s->step_graph = nullptr;
-        hipGraph_t g = nullptr;
-        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        decode_core(m, s, true);
-        launch_argmax_step(argmax_params(m, s, true, o->eot, o->ignore_eot, true), st);
-        HIPCHK(hipStreamEndCapture(st, &g));
-        hipError_t ge = hipGraphInstantiate(&s->step_graph, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        if (ge != hipSuccess) return fail(WM_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ge));
-        s->graph_eot = o->eot;
-        s->graph_ignore = o->ignore_eot;
+    const bool recapture = !s->graphs_valid || s->graph_eot != o->eot || s->graph_ignore != o->ignore_eot;
+    const int first_pos = o->pos_mode == WM_POS_REF ? o->n_prompt - 1 : o->n_prompt;
+    for (auto& ln : s->lanes) {
+        const DecView v{ln.b0, ln.nb, ln.st, ln.ctl};
+        // prefill (whisper.mojo:195, start_pos=0): the q_len = n_prompt causal block equals n_prompt single-token steps
+        for (int i = 0; i < o->n_prompt; ++i) {
+            launch_set_step(v.ctl, i, 1, s->pos.as<int>() + v.b0, i, s->tok.as<int>() + v.b0, o->prompt[i], v.nb, v.st);
+            decode_core(m, s, v, i == o->n_prompt - 1);
+        }
+        launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot), v.st);  // :198-203
+        // incremental steps: start_pos = current_len - 1 (reference, :217) or current_len (HF)
+        launch_set_step(v.ctl, o->n_prompt, 1, s->pos.as<int>() + v.b0, first_pos, nullptr, 0, v.nb, v.st);
+        // steady state: one captured graph per lane = [37 decode-step launches + argmax/bookkeeping]; every per-step
+        // quantity (token, position, cache length) lives in HBM, so the same graph is replayed for every token
+        if (!no_graph && (recapture || !ln.graph[0])) {
+            for (auto& ge : ln.graph) {
+                if (ge) (void)hipGraphExecDestroy(ge);
+                ge = nullptr;
+            }
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamBeginCapture(v.st, hipStreamCaptureModeThreadLocal));
+            decode_core(m, s, v, true);
+            launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, true), v.st);
+            HIPCHK(hipStreamEndCapture(v.st, &g));
+            // hipGraphLaunch (ROCm 7.2) blocks the host while the previous launch of the SAME exec is in flight, so the
+            // step is instantiated NEXEC times and the instances are launched round-robin: the host runs ahead again
+            hipError_t ge = hipSuccess;
+            for (int k = 0; k < wm_state::Lane::NEXEC && ge == hipSuccess; ++k) ge = hipGraphInstantiate(&ln.graph[k], g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (ge != hipSuccess) return fail(WM_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ge));
+        }
     }
-    StepCtl* h_ctl = nullptr;
-    HIPCHK(hipHostMalloc((void**)&h_ctl, sizeof(StepCtl), 0));
+    s->graphs_valid = !no_graph;
+    s->graph_eot = o->eot;
+    s->graph_ignore = o->ignore_eot;
+
+    StepCtl* h_ctl = s->h_ctl;
     int rc = 0;
-    for (int it = 0; it < o->max_loop; ++it) {
-        if (!o->ignore_eot && (it % 8) == 0) {  // "if next_token == eot: break" for the whole batch
-            hipError_t e = hipMemcpyAsync(h_ctl, ctl, sizeof(StepCtl), hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            if (e != hipSuccess) {
-                rc = fail(WM_E_HIP, "poll: %s", hipGetErrorString(e));
-                break;
+    static const bool trace_host = getenv("WM_TRACE_HOST") != nullptr;
+    const auto t_loop0 = std::chrono::steady_clock::now();
+    for (int it = 0; it < o->max_loop && !rc; ++it) {
+        if (!o->ignore_eot && (it % 8) == 0) {  // "if next_token == eot: break", for the whole batch
+            int fin = 0;
+            for (auto& ln : s->lanes) {
+                hipError_t e = hipMemcpyAsync(h_ctl, ln.ctl, sizeof(StepCtl), hipMemcpyDeviceToHost, ln.st);
+                if (e == hipSuccess) e = hipStreamSynchronize(ln.st);
+                if (e != hipSuccess) {
+                    rc = fail(WM_E_HIP, "poll: %s", hipGetErrorString(e));
+                    break;
+                }
+                fin += h_ctl->n_finished;
             }
-            if (h_ctl->n_finished >= B) break;
+            if (rc || fin >= B) break;
         }
-        if (s->step_graph && !no_graph) {
-            hipError_t e = hipGraphLaunch(s->step_graph, st);
-            if (e != hipSuccess) {
-                rc = fail(WM_E_HIP, "hipGraphLaunch: %s", hipGetErrorString(e));
-                break;
+        for (auto& ln : s->lanes) {  // lanes are independent: launches interleave, the GPU overlaps them
+            if (ln.graph[0] && !no_graph) {
+                hipError_t e = hipGraphLaunch(ln.graph[it % wm_state::Lane::NEXEC], ln.st);
+                if (e != hipSuccess) {
+                    rc = fail(WM_E_HIP, "hipGraphLaunch: %s", hipGetErrorString(e));
+                    break;
+                }
+            } else {
+                const DecView v{ln.b0, ln.nb, ln.st, ln.ctl};
+                decode_core(m, s, v, true);
+                launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, true), v.st);
             }
-        } else {
-            decode_core(m, s, true);
-            launch_argmax_step(argmax_params(m, s, true, o->eot, o->ignore_eot, true), st);
         }
     }
-    (void)hipHostFree(h_ctl);
     if (rc) return rc;
+    if (trace_host) {
+        const auto t1 = std::chrono::steady_clock::now();
+        for (auto& ln : s->lanes) (void)hipStreamSynchronize(ln.st);
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[wm] decode loop: %d iterations x %zu lanes: host enqueue %.1f us/iteration, drain %.1f ms\n", o->max_loop,
+                s->lanes.size(), std::chrono::duration<double>(t1 - t_loop0).count() * 1e6 / std::max(1, o->max_loop),
+                std::chrono::duration<double>(t2 - t1).count() * 1e3);
+    }
+    for (auto& ln : s->lanes) {  // join: the main stream continues after every lane
+        HIPCHK(hipEventRecord(ln.done, ln.st));
+        HIPCHK(hipStreamWaitEvent(st0, ln.done, 0));
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1000,19 +1101,21 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
     HIPCHK(hipEventCreate(&e1));
     const int L = m->cfg.dims.n_layers;
     if (which == WM_KERNEL_CROSS_ATTN) {
-        for (int i = 0; i < L; ++i) launch_cross_attn(m, s, i);  // warm-up
+        const DecView v = whole_batch(m, s);
+        for (int i = 0; i < L; ++i) launch_cross_attn(m, s, i, v);  // warm-up
         HIPCHK(hipEventRecord(e0, st));
-        for (int i = 0; i < reps; ++i) launch_cross_attn(m, s, i % L);  // cycles the layers: 4 x 295 MB > 256 MB L3
+        for (int i = 0; i < reps; ++i) launch_cross_attn(m, s, i % L, v);  // cycles the layers: 4 x 295 MB > 256 MB L3
         HIPCHK(hipEventRecord(e1, st));
     } else if (which == WM_KERNEL_DECODE_STEP) {
         const int len0 = std::max(s->host_len, 1);
+        const DecView v = whole_batch(m, s);
         launch_set_step(s->ctl.as<StepCtl>(), len0, 1, nullptr, 0, nullptr, 0, s->B, st);
-        decode_core(m, s, true);
+        decode_core(m, s, v, true);
         // timed as the transcribe loop runs it: a captured graph of the step, replayed (cache length held constant)
         hipGraph_t g = nullptr;
         hipGraphExec_t ge = nullptr;
         HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        decode_core(m, s, true);
+        decode_core(m, s, v, true);
         HIPCHK(hipStreamEndCapture(st, &g));
         HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         (void)hipGraphDestroy(g);
@@ -1022,6 +1125,60 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
         HIPCHK(hipEventRecord(e1, st));
         HIPCHK(hipEventSynchronize(e1));
         (void)hipGraphExecDestroy(ge);
+    } else if (which >= 10 && which < 20) {
+        // debug chains (developer experiments): 40-node graphs of small decode kernels, replayed `reps` times
+        const wm_dims& c = m->cfg.dims;
+        DecLayer& w0 = m->dec[0];
+        auto lin = [&](bool ln) {
+            DecLinearParams p{};
+            p.x = s->dattn.as<float>();
+            p.ldx = c.d_model;
+            if (ln) {
+                p.ln_g = w0.ln1_g.as<float>();
+                p.ln_b = w0.ln1_b.as<float>();
+            }
+            p.W = w0.so_w.p;
+            p.N = c.d_model;
+            p.K = c.d_model;
+            p.B = s->B;
+            p.bias = w0.so_b.as<float>();
+            p.out = s->dq.as<float>();
+            p.ldo = c.d_model;
+            dec_linear_dispatch(m->cfg.compute_dtype, p, st);
+        };
+        auto emb = [&]() { launch_dec_embed(m->tok_emb_f.as<float>(), m->dec_pos.as<float>(), s->tok.as<int>(), s->pos.as<int>(), s->dx.as<float>(), s->B, c.d_model, st); };
+        auto comb = [&]() { launch_attn_combine(s->part_o.as<float>(), s->part_ml.as<float>(), s->dattn.as<float>(), s->B, s->nsplit, c.n_heads, c.d_model, st); };
+        auto setk = [&]() { launch_set_step(s->ctl.as<StepCtl>() + 7, 0, 1, nullptr, 0, nullptr, 0, s->B, st); };
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < 40; ++i) {
+            switch (which) {
+                case 10: emb(); break;
+                case 11: setk(); break;
+                case 12: comb(); break;
+                case 13: lin(false); break;
+                case 14: lin(true); break;
+                case 15: if (i % 3 == 0) emb(); else if (i % 3 == 1) comb(); else setk(); break;
+                case 16: if (i % 2 == 0) lin(true); else comb(); break;
+                default: setk(); break;
+            }
+        }
+        HIPCHK(hipStreamEndCapture(st, &g));
+        HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+        HIPCHK(hipGraphLaunch(ge, st));
+        HIPCHK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) HIPCHK(hipGraphLaunch(ge, st));
+        HIPCHK(hipEventRecord(e1, st));
+        HIPCHK(hipEventSynchronize(e1));
+        (void)hipGraphExecDestroy(ge);
+        float ms40 = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms40, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_us = ms40 * 1000.0f / (float)(reps * 40);
+        return 0;
     } else if (which == WM_KERNEL_ENCODER) {
         if (!s->last_mel) return fail(WM_E_STATE, "no mel was encoded into this state");
         WMCHK(run_encoder(m, s, s->last_mel, s->B));
@@ -1083,7 +1240,16 @@ extern "C" int wm_op_matmul_nt(float* C, const float* A, const float* Bm, const 
         HIPCHK(hipMemcpy(C, c.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     } else {  // skinny path: the decode-step linear kernel
         const int Np = (N + 15) / 16 * 16;
-        const int Kp = (K + 127) / 128 * 128;  // the kernel splits K over 4 waves in 32-deep steps: zero-pad K
+        // the kernel splits K over NW <= 16 waves, <= 4 k-steps of 32 each: zero-pad K to the next such size
+        auto splittable = [](int k) {
+            const int ks = k / 32;
+            for (int c = 16; c >= 1; --c)
+                if (ks % c == 0 && ks / c <= 4) return true;
+            return false;
+        };
+        int Kp = (K + 127) / 128 * 128;
+        while (!splittable(Kp)) Kp += 128;
+        if (Kp > 2048) return fail(WM_E_ARG, "K too large for the skinny path (<= 2048)");
         std::vector<float> Apad((size_t)M * Kp, 0.f), Bpad((size_t)N * Kp, 0.f);
         for (int i = 0; i < M; ++i) memcpy(&Apad[(size_t)i * Kp], A + (size_t)i * K, (size_t)K * 4);
         for (int i = 0; i < N; ++i) memcpy(&Bpad[(size_t)i * Kp], Bm + (size_t)i * K, (size_t)K * 4);
