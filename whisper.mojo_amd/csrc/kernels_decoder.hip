@@ -208,10 +208,26 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
     constexpr int CHK = sizeof(TW) == 2 ? KS : KS / 2;  // k-steps whose weight fragments are in flight together
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     TW* xs = reinterpret_cast<TW*>(smem_raw);  // [NRB*16][PITCH]
+    __shared__ float s_av[4][NRB * 16];
+    __shared__ int s_ai[4][NRB * 16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int row0 = blockIdx.y * NRB * 16;
     const int nrows = min(NRB * 16, p.B - row0);
+    const int n0 = blockIdx.x * 128 + w * 32;
+    const TW* wp[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        int wr = n0 + nb * 16 + r16;
+        wr = wr < p.N ? wr : p.N - 1;
+        wp[nb] = (const TW*)p.W + (size_t)wr * K + g * 8;
+    }
+    // the embedding rows do not depend on the activations: request the first chunk before the LayerNorm staging
+    Frag<TW> wf[2][CHK];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + i * 32);
 
     {  // LN + convert -> LDS.  thread t: row t>>2 (+64 per pass), quarter t&3 of the row, float4 index q + 4*i
         for (int rbase = 0; rbase < NRB * 16; rbase += 64) {
@@ -252,14 +268,6 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
     }
     __syncthreads();
 
-    const int n0 = blockIdx.x * 128 + w * 32;
-    const TW* wp[2];
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        int wr = n0 + nb * 16 + r16;
-        wr = wr < p.N ? wr : p.N - 1;
-        wp[nb] = (const TW*)p.W + (size_t)wr * K + g * 8;
-    }
     f32x4 acc[2][NRB];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
@@ -267,11 +275,12 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
         for (int rb = 0; rb < NRB; ++rb) acc[nb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < KS / CHK; ++c) {
-        Frag<TW> wf[2][CHK];
+        if (c > 0) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + (c * CHK + i) * 32);
+                for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + (c * CHK + i) * 32);
+        }
 #pragma unroll
         for (int i = 0; i < CHK; ++i) {
 #pragma unroll
@@ -282,15 +291,68 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
             }
         }
     }
+    // acc[nb][rb][r] = logits[row0 + 16 rb + r16][n0 + 16 nb + 4 g + r]
+    if (p.out) {
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) {
-        const int lr = rb * 16 + r16;
-        if (lr < nrows) {
+        for (int rb = 0; rb < NRB; ++rb) {
+            const int lr = rb * 16 + r16;
+            if (lr < nrows) {
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const int n = n0 + nb * 16 + g * 4;
-                if (n < p.ldo) *reinterpret_cast<f32x4*>(p.out + (size_t)(row0 + lr) * p.ldo + n) = acc[nb][rb];
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int n = n0 + nb * 16 + g * 4;
+                    if (n < p.ldo) *reinterpret_cast<f32x4*>(p.out + (size_t)(row0 + lr) * p.ldo + n) = acc[nb][rb];
+                }
             }
+        }
+    }
+    if (p.amax_val) {
+        // fused argmax, stage 1 (whisper_tensor.mojo:431-439: lowest index wins): this workgroup's best of its 128
+        // columns per utterance.  Lane-local over 8 columns, 2 butterfly steps over the 4 lanes of a row, LDS over waves.
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + nb * 16 + g * 4 + r;
+                    const float v = acc[nb][rb][r];
+                    if (n < p.N && v > bv) {  // n increases through the loop: strict '>' keeps the lowest index
+                        bv = v;
+                        bi = n;
+                    }
+                }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float v2 = __shfl_xor(bv, o, 64);
+                const int i2 = __shfl_xor(bi, o, 64);
+                if (v2 > bv || (v2 == bv && i2 < bi)) {
+                    bv = v2;
+                    bi = i2;
+                }
+            }
+            if (g == 0) {
+                s_av[w][rb * 16 + r16] = bv;
+                s_ai[w][rb * 16 + r16] = bi;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < NRB * 16 && (int)threadIdx.x < nrows) {
+            float bv = s_av[0][threadIdx.x];
+            int bi = s_ai[0][threadIdx.x];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const float v2 = s_av[k][threadIdx.x];
+                const int i2 = s_ai[k][threadIdx.x];
+                if (v2 > bv || (v2 == bv && i2 < bi)) {
+                    bv = v2;
+                    bi = i2;
+                }
+            }
+            const size_t o = (size_t)(row0 + threadIdx.x) * p.amax_stride + blockIdx.x;
+            p.amax_val[o] = bv;
+            p.amax_idx[o] = bi;
         }
     }
 }
@@ -548,11 +610,53 @@ __device__ __forceinline__ void argmax_block(const float* row, int V, float& bes
     best = mv;
     bidx = mi;
 }
+// stage 2 of the fused argmax: best of the per-workgroup partials of one utterance (ties -> lowest index)
+__device__ __forceinline__ void argmax_partials(const float* pv, const int* pi, int n, float& best, int& bidx) {
+    __shared__ float s_v[16];
+    __shared__ int s_i[16];
+    float mv = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = pv[i];
+        const int ix = pi[i];
+        if (v > mv || (v == mv && ix < mi)) {
+            mv = v;
+            mi = ix;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(mv, o, 64);
+        const int i2 = __shfl_xor(mi, o, 64);
+        if (v2 > mv || (v2 == mv && i2 < mi)) {
+            mv = v2;
+            mi = i2;
+        }
+    }
+    const int wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_v[wid] = mv;
+        s_i[wid] = mi;
+    }
+    __syncthreads();
+    mv = s_v[0];
+    mi = s_i[0];
+    for (int k = 1; k < nw; ++k)
+        if (s_v[k] > mv || (s_v[k] == mv && s_i[k] < mi)) {
+            mv = s_v[k];
+            mi = s_i[k];
+        }
+    best = mv;
+    bidx = mi;
+}
 __global__ __launch_bounds__(1024) void argmax_step_kernel(ArgmaxParams p) {
     const int b = blockIdx.x;
     float best;
     int idx;
-    argmax_block(p.logits + (size_t)b * p.ldl, p.V, best, idx);
+    if (p.pval)
+        argmax_partials(p.pval + (size_t)b * p.npart, p.pidx + (size_t)b * p.npart, p.npart, best, idx);
+    else
+        argmax_block(p.logits + (size_t)b * p.ldl, p.V, best, idx);
     if (threadIdx.x == 0) {
         p.next[b] = idx;
         if (p.advance) {  // current_len += 1 (layers.mojo:143), position += 1: nothing else in this launch reads them
@@ -570,7 +674,7 @@ __global__ __launch_bounds__(1024) void argmax_step_kernel(ArgmaxParams p) {
     }
 }
 void launch_argmax_step(const ArgmaxParams& p, hipStream_t st) {
-    hipLaunchKernelGGL(argmax_step_kernel, dim3(p.B), dim3(1024), 0, st, p);
+    hipLaunchKernelGGL(argmax_step_kernel, dim3(p.B), dim3(p.pval ? 256 : 1024), 0, st, p);
 }
 __global__ __launch_bounds__(1024) void argmax_plain_kernel(const float* t, int n, int* idx) {
     float best;

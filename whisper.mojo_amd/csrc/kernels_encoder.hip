@@ -6,6 +6,8 @@
 // layers.mojo:273-342, layer_norm whisper_tensor.mojo:249-285, residual adds layers.mojo:457-461,483-487,513-517.
 #include "wm_kernels.h"
 
+#include <cstdlib>
+
 namespace wm {
 
 // ------------------------------------------------------------------------------------------------------------
@@ -120,8 +122,116 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Same contract, 16-bit operands, LDS-staged (the dense path of BASELINE configs 3-5).
+// 128x128 tile, BK = 64, 256 threads (2x2 waves of 64x64).  Both operand tiles go global -> LDS with
+// global_load_lds_dwordx4 (no VGPR round trip; one wave instruction = 8 rows x 128 B = 1 KiB of lane-linear LDS) into a
+// double buffer; the next K tile's DMA is in flight while this one's fragments are read (ds_read_b128) and multiplied.
+// LDS rows are 128 B, so the 16-byte chunk index is XOR-swizzled with (row & 7) — applied on the per-lane GLOBAL source
+// address (the LDS side of a DMA cannot scatter) and again on the fragment read address.
+template <typename T>
+__device__ __forceinline__ void stage_tile(const T* __restrict__ gbase, long ld, T* lds_tile, int lane, int w) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = w * 4 + j;                       // 1-KiB piece index: rows 8i .. 8i+7
+        const int row = 8 * i + (lane >> 3), cp = lane & 7;
+        const int c = cp ^ (row & 7);                  // logical 16-byte chunk that lives at position cp
+        const T* g = gbase + (size_t)row * ld + c * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(lds_tile + i * 512), 16, 0, 0);
+    }
+}
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) T lds[2][2][128 * 64];  // [buffer][A|W][row][64]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int bm = blockIdx.y * 128, bn = blockIdx.x * 128;
+    const T* A = (const T*)p.A + (size_t)blockIdx.z * p.strideA + (size_t)bm * p.lda;
+    const T* W = (const T*)p.W + (size_t)bn * p.ldw;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = p.K >> 6;
+    stage_tile<T>(A, p.lda, lds[0][0], lane, wid);
+    stage_tile<T>(W, p.ldw, lds[0][1], lane, wid);
+    __syncthreads();  // drains the DMA (vmcnt(0)) and publishes the tile
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) {
+            stage_tile<T>(A + (t + 1) * 64, p.lda, lds[cur ^ 1][0], lane, wid);
+            stage_tile<T>(W + (t + 1) * 64, p.ldw, lds[cur ^ 1][1], lane, wid);
+        }
+        const T* As = lds[cur][0];
+        const T* Ws = lds[cur][1];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag<T> a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra = wm * 64 + i * 16 + r16;
+                a[i] = load_frag<T>(As + ra * 64 + (((ks * 4 + g) ^ (ra & 7)) << 3));
+                const int rb = wn * 64 + i * 16 + r16;
+                b[i] = load_frag<T>(Ws + rb * 64 + (((ks * 4 + g) ^ (rb & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][i] = mma32(b[j], a[i], acc[j][i]);
+        }
+        __syncthreads();  // next tile landed; everyone is done with this one
+        cur ^= 1;
+    }
+
+    // epilogue: acc[j][i][r] = C[m0 + 16i + r16][n0 + 16j + 4g + r]
+    const int m0 = bm + wm * 64, n0 = bn + wn * 64;
+    TO* Cb = (TO*)p.C + (size_t)blockIdx.z * p.strideC;
+    const float* Rb = p.residual ? p.residual + (size_t)blockIdx.z * p.strideR : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + i * 16 + r16;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + j * 16 + g * 4;
+            f32x4 v = acc[j][i];
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], p.gelu_mode);
+            }
+            if (p.pos) v += *reinterpret_cast<const f32x4*>(p.pos + (size_t)m * p.N + n);
+            if (Rb) v += *reinterpret_cast<const f32x4*>(Rb + (size_t)m * p.ldr + n);
+            size_t off;
+            if (p.group_n > 0)
+                off = (size_t)(n / p.group_n) * p.group_stride + (size_t)m * p.ldc + (n % p.group_n);
+            else
+                off = (size_t)m * p.ldc + n;
+            if constexpr (sizeof(TO) == 4) {
+                *reinterpret_cast<f32x4*>((float*)Cb + off) = v;
+            } else {
+                typedef __attribute__((ext_vector_type(4))) TO to4;
+                to4 o = {from_f32<TO>(v[0]), from_f32<TO>(v[1]), from_f32<TO>(v[2]), from_f32<TO>(v[3])};
+                *reinterpret_cast<to4*>(Cb + off) = o;
+            }
+        }
+    }
+}
+
 template <typename T, typename TO> void launch_gemm_nt(const GemmParams& p, int batch, hipStream_t st) {
     dim3 grid(p.N / 128, (p.M + 127) / 128, batch);
+    static const bool no_lds = getenv("WM_GEMM_DIRECT") != nullptr;
+    if constexpr (sizeof(T) == 2) {
+        if (!no_lds && (p.K & 63) == 0) {
+            hipLaunchKernelGGL((gemm_nt_lds_kernel<T, TO>), grid, dim3(256), 0, st, p);
+            return;
+        }
+    }
     hipLaunchKernelGGL((gemm_nt_kernel<T, TO>), grid, dim3(256), 0, st, p);
 }
 

@@ -152,7 +152,8 @@ struct wm_state {
     DevBuf cross_kv;         // [L][2][B][n_ctx][d] kv dtype
     DevBuf self_kv;          // [L][2][B][n_text_ctx][d]
     // decode arena
-    DevBuf dx, dq, dattn, dhid, part_o, part_ml, logits, tok, pos, ctl, out_tokens, n_tokens, finished;
+    DevBuf dx, dq, dattn, dhid, part_o, part_ml, logits, amax_val, amax_idx, tok, pos, ctl, out_tokens, n_tokens, finished;
+    int npart = 0;  // fused-argmax partials per utterance = ceil(vocab / 128)
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -416,7 +417,7 @@ extern "C" void wm_state_free(wm_state* s) {
     if (s->enc_done) (void)hipEventDestroy(s->enc_done);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     DevBuf* bs[] = {&s->mel_dev, &s->mel_t, &s->h1, &s->x, &s->xn, &s->qkv, &s->ao, &s->hid, &s->enc_t, &s->enc_f,
-                    &s->cross_kv, &s->self_kv, &s->dx, &s->dq, &s->dattn, &s->dhid, &s->part_o, &s->part_ml, &s->logits,
+                    &s->cross_kv, &s->self_kv, &s->dx, &s->dq, &s->dattn, &s->dhid, &s->part_o, &s->part_ml, &s->logits, &s->amax_val, &s->amax_idx,
                     &s->tok, &s->pos, &s->ctl, &s->out_tokens, &s->n_tokens, &s->finished};
     for (DevBuf* b : bs) b->release();
     delete s;
@@ -465,6 +466,9 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
     A(s->part_o, (size_t)B * s->nsplit * d * 4);
     A(s->part_ml, (size_t)B * s->nsplit * c.n_heads * 2 * 4);
     A(s->logits, (size_t)B * m->Vpad * 4);
+    s->npart = (c.vocab + 127) / 128;
+    A(s->amax_val, (size_t)B * s->npart * 4);
+    A(s->amax_idx, (size_t)B * s->npart * 4);
     A(s->tok, (size_t)B * 4, true);
     A(s->pos, (size_t)B * 4, true);
     A(s->ctl, sizeof(StepCtl) * 8, true);  // [0] whole-batch control (wm_decode_step), [1..] one per decode lane
@@ -748,7 +752,9 @@ static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v)
     attn_decode_dispatch(m->cfg.kv_dtype, a, v.st);
 }
 
-static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_logits) {
+// want_logits: run the final LN + vocabulary projection.  full_logits: also materialise [B, vocab] fp32 (stage tests,
+// wm_decode_step); the greedy loop only needs the fused-argmax partials.
+static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_logits, bool full_logits = false) {
     const wm_dims& c = m->cfg.dims;
     const int T = m->cfg.compute_dtype, KV = m->cfg.kv_dtype;
     const int B = v.nb;
@@ -868,8 +874,11 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
         p.N = c.vocab;
         p.K = c.d_model;
         p.B = B;
-        p.out = s->logits.as<float>() + (size_t)v.b0 * m->Vpad;
+        p.out = full_logits ? s->logits.as<float>() + (size_t)v.b0 * m->Vpad : nullptr;
         p.ldo = m->Vpad;
+        p.amax_val = s->amax_val.as<float>() + (size_t)v.b0 * s->npart;
+        p.amax_idx = s->amax_idx.as<int>() + (size_t)v.b0 * s->npart;
+        p.amax_stride = s->npart;
         DISPATCH_DT(T, TT, launch_dec_logits<TT>(p, st));
     }
 }
@@ -878,6 +887,9 @@ static ArgmaxParams argmax_params(wm_model* m, wm_state* s, const DecView& v, bo
                                   bool advance = false) {
     ArgmaxParams a{};
     a.logits = s->logits.as<float>() + (size_t)v.b0 * m->Vpad;
+    a.pval = s->amax_val.as<float>() + (size_t)v.b0 * s->npart;
+    a.pidx = s->amax_idx.as<int>() + (size_t)v.b0 * s->npart;
+    a.npart = s->npart;
     a.ldl = m->Vpad;
     a.V = m->cfg.dims.vocab;
     a.B = v.nb;
@@ -919,7 +931,7 @@ extern "C" int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, i
         HIPCHK(hipMemcpyAsync(s->tok.p, col.data(), B * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(s->pos.p, pos.data(), B * 4, hipMemcpyHostToDevice, st));
         launch_set_step(v.ctl, s->host_len, 1, nullptr, 0, nullptr, 0, B, st);
-        decode_core(m, s, v, i == q_len - 1);
+        decode_core(m, s, v, i == q_len - 1, true);
         HIPCHK(hipStreamSynchronize(st));  // col/pos are reused next iteration
         s->host_len += 1;
     }
@@ -1077,12 +1089,13 @@ extern "C" int wm_bench_bytes(wm_model* m, wm_state* s, int which, double* bytes
         // one layer: K and V rows of every utterance once + q in + partials out
         *bytes = B * 2.0 * c.n_audio_ctx * d * ks + B * d * 4 + B * s->nsplit * (d + 2 * H) * 4;
     } else if (which == WM_KERNEL_DECODE_STEP) {
-        // every weight once per step, KV once per utterance, KV write, logits materialised
+        // every weight once per step, KV once per utterance, KV write; logits are NOT materialised
+        // (fused argmax: only B x ceil(V/128) (value, index) partials are written and re-read)
         const double f = c.ffn, L = c.n_layers, V = c.vocab;
         const double p_blk = 8 * d * d + 2 * f * d + (4 + 4 + 1 + 1 + 6) * d + f;  // 2 attn (4 mats each) + mlp + biases + 3 LN
         const double t = s->host_len > 0 ? s->host_len : 50;
         *bytes = ws * (L * (8 * d * d + 2 * f * d) + V * d) + 4 * (L * (p_blk - 8 * d * d - 2 * f * d) + 2 * d) +
-                 B * L * 2 * d * ks * (c.n_audio_ctx + t) + B * L * 2 * d * ks + B * V * 4.0 * 2 + B * 4;
+                 B * L * 2 * d * ks * (c.n_audio_ctx + t) + B * L * 2 * d * ks + B * s->npart * 8.0 * 2 + B * 4;
     } else if (which == WM_KERNEL_ENCODER) {
         *bytes = 0;  // MFMA-bound: see wm_bench_flops in DESIGN.md
     } else {

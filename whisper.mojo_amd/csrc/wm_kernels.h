@@ -56,6 +56,10 @@ struct DecLinearParams {
     int d_model;
     int kv_dtype;  // WM_F32 / WM_BF16 / WM_F16
     const StepCtl* ctl;
+    // dec_logits only: fused argmax stage 1 — per-utterance best (value, column) of each 128-column workgroup
+    float* amax_val;  // [B][amax_stride] or null
+    int* amax_idx;
+    int amax_stride;
 };
 template <typename TW> void launch_dec_linear(const DecLinearParams& p, hipStream_t st);
 template <typename TW> void launch_dec_logits(const DecLinearParams& p, hipStream_t st);
@@ -84,6 +88,9 @@ void launch_dec_embed(const float* tok_emb, const float* pos_emb, const int* tok
 struct ArgmaxParams {
     const float* logits;
     int ldl, V, B;
+    const float* pval;  // non-null: reduce the fused-argmax partials [B][npart] instead of scanning the logits
+    const int* pidx;
+    int npart;
     int* next;        // [B] next token (also the next step's input)
     int* out_tokens;  // [B][out_stride] or null
     int out_stride;
