@@ -66,6 +66,20 @@ def cpu_baseline(cfg, weights, mel, max_loop):
                       "fastest of {8,16,32} OpenMP threads; C restatement of the reference (Mojo toolchain absent)"}
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r1_pmc_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 x2 FETCH correction applied).  Counters need
+    their own serialised profiler passes, so they cannot be collected inside a timed bench run; null for other workloads."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if workload != "tiny_b64_bf16" or not os.path.exists(path):
+        return None
+    try:
+        ks = json.load(open(path))["kernels"]
+        return next(v["traffic_bytes"] for k, v in ks.items() if k.startswith("attn_decode_kernel"))
+    except Exception:
+        return None
+
+
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -177,7 +191,7 @@ def main():
                        "name": args.workload, "utterances_per_gpu": B, "kv_dtype": kdt, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": "attn_decode_kernel (decoder cross-attention, one layer, all utterances)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.workload),
                          "bytes_per_launch": nbytes.value, "us_per_launch": round(us.value, 2)},
             "decode_step": {"us": round(step_us.value, 1), "algorithmic_bytes": step_bytes.value,
                             "GBps": round(step_gbs, 1), "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4)},

@@ -395,15 +395,14 @@ template void launch_dec_logits<f16>(const DecLinearParams&, hipStream_t);
 // attn_combine, or the normalised output directly when the chunk is the whole sequence.
 // Scale after the dot product and max initialised to -1e10 follow layers.mojo:196,212 (the mask branch at :213 is a
 // no-op for j <= len-1 and is omitted).
-template <typename TKV, int LPH, bool FAST, bool NT>
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecParams p) {
+template <typename TKV, int LPH, bool FAST, bool NT, int U>
+__global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecParams p) {
     constexpr int EPL = 64 / LPH;  // elements per lane
-    constexpr int U = 4;
-    __shared__ float s_ml[256][2];
-    __shared__ float s_red[256 * EPL];
+    __shared__ float s_ml[512][2];
+    __shared__ float s_red[512 * EPL];
     const int b = blockIdx.y, split = blockIdx.x;
     const int LPR = p.H * LPH;
-    const int RPS = 256 / LPR;
+    const int RPS = p.rps;  // key rows swept per step = active threads / LPR
     const int len = p.n_keys >= 0 ? p.n_keys : p.ctl->len + 1;
     const int chunk = (len + p.nsplit - 1) / p.nsplit;
     const int j0 = split * chunk;
@@ -520,14 +519,22 @@ template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStrea
     constexpr int LPH = sizeof(TKV) == 4 ? 16 : 8;
     constexpr bool FAST = sizeof(TKV) == 2;
     const int LPR = p.H * LPH;
-    const int RPS = 256 / LPR;
+    AttnDecParams q = p;
+    q.rps = 256 / LPR;  // 512-thread workgroups measured no better for the short self-attention sequence (5.3 vs 5.0 us)
     // block rounded up to whole waves: the spare lanes take no rows (rslot >= RPS) but stay in the DPP groups
-    const dim3 grid(p.nsplit, p.B), block((RPS * LPR + 63) / 64 * 64);
+    const dim3 grid(p.nsplit, p.B), block((q.rps * LPR + 63) / 64 * 64);
     static const bool nt_off = getenv("WM_NO_NT") != nullptr;
-    if (p.n_keys >= 0 && !nt_off)  // the cross-attention K/V stream (1500 rows per utterance, read once per step)
-        hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true>), grid, block, 0, st, p);
-    else
-        hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, false>), grid, block, 0, st, p);
+    static const int u_cross = getenv("WM_ATTN_U") ? atoi(getenv("WM_ATTN_U")) : 4;
+    if (p.n_keys >= 0 && !nt_off) {  // the cross-attention K/V stream (1500 rows per utterance, read once per step)
+        if (u_cross == 8)
+            hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 8>), grid, block, 0, st, q);
+        else if (u_cross == 2)
+            hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 2>), grid, block, 0, st, q);
+        else
+            hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 4>), grid, block, 0, st, q);
+    } else {
+        hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, false, 2>), grid, block, 0, st, q);
+    }
 }
 template void launch_attn_decode<float>(const AttnDecParams&, hipStream_t);
 template void launch_attn_decode<bf16>(const AttnDecParams&, hipStream_t);

@@ -410,8 +410,210 @@ __global__ __launch_bounds__(256) void flash_attn_enc_kernel(const T* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// v2 of the fused encoder attention for 16-bit operands (same math and operand maps as above):
+//   * 128 query rows per workgroup (two 16-row query blocks per wave): every K / V fragment read from LDS feeds two
+//     MFMAs, halving LDS traffic per FLOP;
+//   * K and V tiles are both staged row-major with 16-byte stores; the Vᵀ operand fragment is produced by the
+//     hardware transposing read ds_read_b64_tr_b16 (a 16-lane group reads a 4-key x 16-dim block column-major, which
+//     is exactly the permuted-key fragment: keys 32c+4g+q then 32c+16+4g+q) — no scalar transposed writes;
+//   * the next tile is fetched global -> registers while this one is consumed and lands in the other LDS buffer:
+//     one barrier per tile and no exposed global latency;
+//   * softmax in the exp2 domain (scale·log2e folded into one multiply, v_exp_f32 directly), key mask only on the
+//     last tile.
+__device__ __forceinline__ bf16x4 lds_tr16(const bf16* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+}
+__device__ __forceinline__ f16x4 lds_tr16(const f16* p) {
+    typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 h4;
+    const h4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)p);
+    return __builtin_bit_cast(f16x4, v);
+}
+
+template <typename T, int NW, int QB>
+__global__ __launch_bounds__(NW * 64) void flash_attn_enc_v2_kernel(const T* __restrict__ qkv, T* __restrict__ out, int n_ctx,
+                                                                    int d_model, float scale_log2e, int xcd_remap) {
+    constexpr int PITCH = 72;  // 144-byte rows: conflict-free ds_read_b128 fragments and tr reads
+    __shared__ __attribute__((aligned(16))) T Ks[2][64 * PITCH];
+    __shared__ __attribute__((aligned(16))) T Vs[2][64 * PITCH];
+    typedef __attribute__((ext_vector_type(8))) T t8;
+    typedef __attribute__((ext_vector_type(4))) T t4;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    constexpr int ROWS = NW * QB * 16;  // query rows per workgroup
+    int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    if (xcd_remap) {
+        // Workgroups are dealt round-robin over the 8 XCDs (private L2s).  Give every XCD whole (utterance, head) pairs
+        // so the K/V of a pair is fetched into ONE L2 and re-read there by all of the pair's query tiles.
+        const int nq = gridDim.x, npair = gridDim.y * gridDim.z;  // host guarantees npair % 8 == 0
+        const int lin = blockIdx.x + nq * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int xcd = lin & 7, idx = lin >> 3;
+        const int pair = xcd * (npair >> 3) + idx / nq;
+        qt = idx % nq;
+        h = pair % gridDim.y;
+        b = pair / gridDim.y;
+    }
+    const size_t ld = (size_t)3 * d_model;
+    const T* base = qkv + (size_t)b * n_ctx * ld;
+    const T* kbase = base + d_model + h * 64;
+    const T* vbase = base + 2 * d_model + h * 64;
+
+    Frag<T> qf[QB][2];
+    int q_row[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        q_row[qb] = qt * ROWS + wid * (QB * 16) + qb * 16 + r16;
+        const int q_ld = q_row[qb] < n_ctx ? q_row[qb] : n_ctx - 1;
+#pragma unroll
+        for (int dc = 0; dc < 2; ++dc) qf[qb][dc] = load_frag<T>(base + (size_t)q_ld * ld + h * 64 + dc * 32 + g * 8);
+    }
+    f32x4 o[QB][4];
+    float m_run[QB], l_run[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = -1e30f;
+        l_run[qb] = 0.f;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) o[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // staging map: 512 16-byte chunks per tile and operand; thread t owns chunks t (+ NW*64 when 4 waves)
+    constexpr int NIT = 512 / (NW * 64);
+    const int skey[2] = {(int)threadIdx.x >> 3, ((int)threadIdx.x + 256) >> 3};
+    const int sdch = threadIdx.x & 7;
+    t8 kreg[NIT], vreg[NIT];
+    auto fetch = [&](int key0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int krow = key0 + skey[it];
+            krow = krow < n_ctx ? krow : n_ctx - 1;
+            kreg[it] = *reinterpret_cast<const t8*>(kbase + (size_t)krow * ld + sdch * 8);
+            vreg[it] = *reinterpret_cast<const t8*>(vbase + (size_t)krow * ld + sdch * 8);
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            *reinterpret_cast<t8*>(&Ks[buf][skey[it] * PITCH + sdch * 8]) = kreg[it];
+            *reinterpret_cast<t8*>(&Vs[buf][skey[it] * PITCH + sdch * 8]) = vreg[it];
+        }
+    };
+    const int n_tiles = (n_ctx + 63) / 64;
+    fetch(0);
+    park(0);
+    __syncthreads();
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < n_tiles) fetch((t + 1) * 64);
+        const T* Kt = Ks[buf];
+        const T* Vt = Vs[buf];
+        // Sᵀ = K·Qᵀ
+        f32x4 sc[QB][4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            Frag<T> kf0 = load_frag<T>(&Kt[(kb * 16 + r16) * PITCH + g * 8]);
+            Frag<T> kf1 = load_frag<T>(&Kt[(kb * 16 + r16) * PITCH + 32 + g * 8]);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                z = mma32(kf0, qf[qb][0], z);
+                sc[qb][kb] = mma32(kf1, qf[qb][1], z);
+            }
+        }
+        const bool last = t == n_tiles - 1;
+        Frag<T> pf[QB][2];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float tmax = -1e30f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = sc[qb][kb][r] * scale_log2e;
+                    if (last && t * 64 + kb * 16 + g * 4 + r >= n_ctx) v = -1e30f;
+                    sc[qb][kb][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run[qb], tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+            m_run[qb] = m_new;
+            float psum = 0.f;
+            float pv[2][8];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pe = __builtin_amdgcn_exp2f(sc[qb][kb][r] - m_new);
+                    psum += pe;
+                    pv[kb >> 1][(kb & 1) * 4 + r] = pe;
+                }
+            l_run[qb] = l_run[qb] * alpha + psum;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) o[qb][db] *= alpha;
+            pf[qb][0] = make_frag<T>(pv[0]);
+            pf[qb][1] = make_frag<T>(pv[1]);
+        }
+        // Oᵀ += Vᵀ·Pᵀ : Vᵀ fragments by transposing reads of the row-major V tile
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const T* vp = &Vt[(32 * c + 4 * g + (r16 >> 2)) * PITCH + db * 16 + (r16 & 3) * 4];
+                const t4 lo = lds_tr16(vp);
+                const t4 hi = lds_tr16(vp + 16 * PITCH);
+                Frag<T> vf;
+                vf.v = t8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) o[qb][db] = mma32(vf, pf[qb][c], o[qb][db]);
+            }
+        if (t + 1 < n_tiles) park(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        float l = l_run[qb];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        if (q_row[qb] < n_ctx) {
+            T* orow = out + ((size_t)b * n_ctx + q_row[qb]) * d_model + h * 64;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                t4 ov = {from_f32<T>(o[qb][db][0] * inv), from_f32<T>(o[qb][db][1] * inv), from_f32<T>(o[qb][db][2] * inv),
+                         from_f32<T>(o[qb][db][3] * inv)};
+                *reinterpret_cast<t4*>(orow + db * 16 + g * 4) = ov;
+            }
+        }
+    }
+}
+
 template <typename T>
 void launch_flash_attn_enc(const void* qkv, void* out, int B, int H, int n_ctx, float scale, hipStream_t st) {
+    static const bool v1 = getenv("WM_ATTN_V1") != nullptr;
+    // measured (tiny, 8 utterances per pass, encoder ms per 64 clips): 8 waves x 1 q-block 9.73 | 4x1 9.75 | 4x2 10.13 | 8x2 10.31
+    static const int var = getenv("WM_ATTN_VAR") ? atoi(getenv("WM_ATTN_VAR")) : 1;
+    static const bool no_xcd = getenv("WM_ATTN_NOXCD") != nullptr;
+    if constexpr (sizeof(T) == 2) {
+        if (!v1) {
+            const int remap = (!no_xcd && (B * H) % 8 == 0) ? 1 : 0;
+            const float sl = scale * 1.4426950408889634f;
+            if (var == 1) {
+                dim3 grid((n_ctx + 127) / 128, H, B);
+                hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 8, 1>), grid, dim3(512), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, remap);
+            } else if (var == 2) {
+                dim3 grid((n_ctx + 255) / 256, H, B);
+                hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 8, 2>), grid, dim3(512), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, remap);
+            } else if (var == 3) {
+                dim3 grid((n_ctx + 63) / 64, H, B);
+                hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 4, 1>), grid, dim3(256), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, remap);
+            } else {
+                dim3 grid((n_ctx + 127) / 128, H, B);
+                hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 4, 2>), grid, dim3(256), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, remap);
+            }
+            return;
+        }
+    }
     dim3 grid((n_ctx + 63) / 64, H, B);
     constexpr bool FAST = sizeof(T) == 2;
     hipLaunchKernelGGL((flash_attn_enc_kernel<T, FAST>), grid, dim3(256), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64,

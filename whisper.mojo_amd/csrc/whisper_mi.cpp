@@ -482,7 +482,9 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
         return rc;
     }
     {  // decode lanes
-        int nl = B >= 32 ? 2 : 1;
+        // measured on MI355X (round 1): 2 lanes 49.1 ms vs 1 lane 47.4 ms per 64-clip pass — kernel boundaries of one
+        // queue also stall the other queue's kernels, so extra lanes stay opt-in (WM_DEC_LANES)
+        int nl = 1;
         if (const char* e = getenv("WM_DEC_LANES")) nl = std::max(1, std::min(4, atoi(e)));
         nl = std::min(nl, (B + 15) / 16);
         s->lanes.resize(nl);
@@ -960,6 +962,8 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o) 
     HIPCHK(hipMemsetAsync(s->finished.p, 0, B * 4, st0));
     HIPCHK(hipMemsetAsync(s->ctl.p, 0, s->ctl.bytes, st0));
     HIPCHK(hipStreamSynchronize(st0));  // rows / nt are pageable host memory; also: encoder + cross K/V complete
+    static const bool trace_phase = getenv("WM_TRACE_HOST") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
 
     static const bool no_graph = getenv("WM_NO_GRAPH") != nullptr;
     const bool recapture = !s->graphs_valid || s->graph_eot != o->eot || s->graph_ignore != o->ignore_eot;
@@ -998,6 +1002,10 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o) 
     s->graph_eot = o->eot;
     s->graph_ignore = o->ignore_eot;
 
+    if (trace_phase) {
+        for (auto& ln : s->lanes) (void)hipStreamSynchronize(ln.st);
+        fprintf(stderr, "[wm] prefill (+graph capture if any): %.3f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count() * 1e3);
+    }
     StepCtl* h_ctl = s->h_ctl;
     int rc = 0;
     static const bool trace_host = getenv("WM_TRACE_HOST") != nullptr;
@@ -1070,8 +1078,15 @@ extern "C" int wm_transcribe(wm_model* m, const float* mel, int mel_on_device, i
         HIPCHK(hipMemcpyAsync(s->mel_dev.p, mel, (size_t)B * c.n_mels * 2 * c.n_audio_ctx * 4, hipMemcpyHostToDevice, m->stream));
         mel_dev = s->mel_dev.as<float>();
     }
+    const auto tt0 = std::chrono::steady_clock::now();
     WMCHK(run_encoder(m, s, mel_dev, B));
     s->has_enc = s->has_cross = true;
+    if (getenv("WM_TRACE_HOST")) {
+        const auto tt1 = std::chrono::steady_clock::now();
+        (void)hipStreamSynchronize(m->stream);
+        fprintf(stderr, "[wm] encoder: enqueue %.3f ms, done after %.3f ms\n", std::chrono::duration<double>(tt1 - tt0).count() * 1e3,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - tt0).count() * 1e3);
+    }
     WMCHK(transcribe_decode(m, s, o));
     HIPCHK(hipMemcpy2DAsync(tokens_out, (size_t)total * 4, s->out_tokens.p, (size_t)s->out_stride * 4, (size_t)total * 4, B, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipMemcpyAsync(n_tokens, s->n_tokens.p, B * 4, hipMemcpyDeviceToHost, m->stream));
@@ -1138,6 +1153,86 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
         HIPCHK(hipEventRecord(e1, st));
         HIPCHK(hipEventSynchronize(e1));
         (void)hipGraphExecDestroy(ge);
+    } else if (which >= 20 && which < 40) {
+        // debug chains of the REAL decode-step launches (layer 0 shapes), 40 per graph
+        const wm_dims& c = m->cfg.dims;
+        const DecView v = whole_batch(m, s);
+        const int KVd = m->cfg.kv_dtype, Td = m->cfg.compute_dtype;
+        DecLayer& w0 = m->dec[0];
+        const size_t ks = dt_size(KVd), dd = c.d_model;
+        const size_t self_l = (size_t)s->B * c.n_text_ctx * dd;
+        void* sk = s->self_kv.p;
+        void* sv = off_bytes(s->self_kv, self_l * ks);
+        auto one = [&](int kind) {
+            DecLinearParams p{};
+            p.B = s->B;
+            switch (kind) {
+                case 20:  // LN1 + QKV + cache append
+                    p.x = s->dx.as<float>(); p.ldx = c.d_model; p.ln_g = w0.ln1_g.as<float>(); p.ln_b = w0.ln1_b.as<float>();
+                    p.W = w0.sqkv_w.p; p.N = 3 * c.d_model; p.K = c.d_model; p.bias = w0.sqkv_b.as<float>(); p.out = s->dq.as<float>();
+                    p.ldo = c.d_model; p.kcache = sk; p.vcache = sv; p.kv_batch_stride = (long)((size_t)c.n_text_ctx * dd);
+                    p.d_model = c.d_model; p.kv_dtype = KVd; p.ctl = v.ctl;
+                    dec_linear_dispatch(Td, p, st);
+                    break;
+                case 21: {  // self attention at the current length
+                    AttnDecParams a{};
+                    a.q = s->dq.as<float>(); a.K = sk; a.V = sv; a.batch_stride = (long)((size_t)c.n_text_ctx * dd); a.n_keys = -1;
+                    a.ctl = v.ctl; a.nsplit = 1; a.scale = 0.125f; a.direct_out = s->dattn.as<float>(); a.H = c.n_heads; a.d = c.d_model; a.B = s->B;
+                    attn_decode_dispatch(KVd, a, st);
+                    break;
+                }
+                case 22:  // o-proj + residual
+                    p.x = s->dattn.as<float>(); p.ldx = c.d_model; p.W = w0.so_w.p; p.N = c.d_model; p.K = c.d_model; p.bias = w0.so_b.as<float>();
+                    p.residual = s->dx.as<float>(); p.ldr = c.d_model; p.out = s->dx.as<float>(); p.ldo = c.d_model;
+                    dec_linear_dispatch(Td, p, st);
+                    break;
+                case 23:  // LNx + q
+                    p.x = s->dx.as<float>(); p.ldx = c.d_model; p.ln_g = w0.lnx_g.as<float>(); p.ln_b = w0.lnx_b.as<float>(); p.W = w0.cq_w.p;
+                    p.N = c.d_model; p.K = c.d_model; p.bias = w0.cq_b.as<float>(); p.out = s->dq.as<float>(); p.ldo = c.d_model;
+                    dec_linear_dispatch(Td, p, st);
+                    break;
+                case 24: launch_cross_attn(m, s, 0, v); break;
+                case 25: launch_attn_combine(s->part_o.as<float>(), s->part_ml.as<float>(), s->dattn.as<float>(), s->B, s->nsplit, c.n_heads, c.d_model, st); break;
+                case 26:  // LN2 + fc1 + gelu
+                    p.x = s->dx.as<float>(); p.ldx = c.d_model; p.ln_g = w0.ln2_g.as<float>(); p.ln_b = w0.ln2_b.as<float>(); p.W = w0.fc1_w.p;
+                    p.N = c.ffn; p.K = c.d_model; p.bias = w0.fc1_b.as<float>(); p.act = 1; p.gelu_mode = m->cfg.gelu_mode; p.out = s->dhid.as<float>(); p.ldo = c.ffn;
+                    dec_linear_dispatch(Td, p, st);
+                    break;
+                case 27:  // fc2 + residual
+                    p.x = s->dhid.as<float>(); p.ldx = c.ffn; p.W = w0.fc2_w.p; p.N = c.d_model; p.K = c.ffn; p.bias = w0.fc2_b.as<float>();
+                    p.residual = s->dx.as<float>(); p.ldr = c.d_model; p.out = s->dx.as<float>(); p.ldo = c.d_model;
+                    dec_linear_dispatch(Td, p, st);
+                    break;
+                case 28:  // final LN + logits + argmax partials
+                    p.x = s->dx.as<float>(); p.ldx = c.d_model; p.ln_g = m->dec_ln_g.as<float>(); p.ln_b = m->dec_ln_b.as<float>();
+                    p.W = Td == WM_F32 ? m->tok_emb_f.p : m->tok_emb_t.p; p.N = c.vocab; p.K = c.d_model; p.out = nullptr; p.ldo = m->Vpad;
+                    p.amax_val = s->amax_val.as<float>(); p.amax_idx = s->amax_idx.as<int>(); p.amax_stride = s->npart;
+                    DISPATCH_DT(Td, TT, launch_dec_logits<TT>(p, st));
+                    break;
+                case 29: launch_argmax_step(argmax_params(m, s, v, false, -1, 1), st); break;
+                default: break;
+            }
+        };
+        launch_set_step(v.ctl, 60, 1, nullptr, 0, nullptr, 0, s->B, st);  // a mid-run cache length
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < 40; ++i) one(which);
+        HIPCHK(hipStreamEndCapture(st, &g));
+        HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+        HIPCHK(hipGraphLaunch(ge, st));
+        HIPCHK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) HIPCHK(hipGraphLaunch(ge, st));
+        HIPCHK(hipEventRecord(e1, st));
+        HIPCHK(hipEventSynchronize(e1));
+        (void)hipGraphExecDestroy(ge);
+        float ms40 = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms40, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_us = ms40 * 1000.0f / (float)(reps * 40);
+        return 0;
     } else if (which >= 10 && which < 20) {
         // debug chains (developer experiments): 40-node graphs of small decode kernels, replayed `reps` times
         const wm_dims& c = m->cfg.dims;

@@ -77,6 +77,7 @@ struct AttnDecParams {
     float* part_ml;     // [B][nsplit][H][2]
     float* direct_out;  // non-null (nsplit must be 1): write the normalised output [B][d] here, skip the partials
     int H, d, B;
+    int rps;  // filled by the launcher
 };
 template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStream_t st);
 void launch_attn_combine(const float* part_o, const float* part_ml, float* out, int B, int nsplit, int H, int d,
