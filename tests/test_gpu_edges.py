@@ -1,0 +1,112 @@
+"""GPU edge cases (-m gpu): ragged batch sizes around the 16-utterance MFMA row block, degenerate decode options,
+Whisper-base at full size, 1-vs-N-rank equivalence of the sharded path (ranks emulated on one GPU)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from whisper_mojo_amd import _lib
+    _lib.lib()
+    return True
+
+
+def make_model(cfg, weights, **kw):
+    from whisper_mojo_amd.loader import WeightLoader
+    from whisper_mojo_amd.whisper import Whisper
+    m = Whisper(cfg, **kw)
+    m.load(WeightLoader.from_array(weights))
+    return m
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_ragged_batches_equal_singles(hip, micro_cfg, micro_weights, dtype):
+    """B = 15 / 17 / 33 straddle the 16-row MFMA blocks of the decode kernels; every utterance must come out exactly as
+    when transcribed alone (nothing in an utterance's arithmetic depends on its neighbours)."""
+    from whisper_mojo_amd import synth
+    mels = synth.synth_mels(micro_cfg, 0, 33)
+    m = make_model(micro_cfg, micro_weights, compute_dtype=dtype, max_batch=33)
+    prompt = (1, 2, 3, 4)
+    full = m.transcribe_batch(mels, prompt=prompt, eot=-1, max_loop=10)
+    singles = {i: m.transcribe_batch(mels[i], prompt=prompt, eot=-1, max_loop=10)[0] for i in (0, 14, 15, 16, 17, 31, 32)}
+    for i, s in singles.items():
+        assert full[i] == s
+    for B in (15, 17):
+        assert m.transcribe_batch(mels[:B], prompt=prompt, eot=-1, max_loop=10) == full[:B]
+
+
+def test_degenerate_decode_options(hip, oracle_mod_, micro_cfg, micro_weights):
+    from whisper_mojo_amd import synth
+    mel = synth.synth_mel(micro_cfg, 1000)
+    m = make_model(micro_cfg, micro_weights)
+    ref = oracle_mod_.OracleModel(micro_cfg, micro_weights)
+    # max_loop = 0: prompt + the one token the prefill yields (whisper.mojo:195-203)
+    assert m.transcribe_batch(mel, prompt=(1, 2, 3, 4), eot=-1, max_loop=0)[0] == ref.transcribe(mel=mel, prompt=(1, 2, 3, 4), eot=-1, max_loop=0).tolist()
+    # single-token prompt
+    got = m.transcribe_batch(mel, prompt=(7,), eot=-1, max_loop=6)[0]
+    assert got == ref.transcribe(mel=mel, prompt=(7,), eot=-1, max_loop=6).tolist() and len(got) == 8
+    # first generated token is eot -> the list is prompt + [eot]
+    first = got[1]
+    assert m.transcribe_batch(mel, prompt=(7,), eot=first, max_loop=6)[0] == [7, first]
+    # the longest stream the decoder context allows
+    n = micro_cfg.n_text_ctx - 4
+    long = m.transcribe_batch(mel, prompt=(1, 2, 3, 4), eot=-1, max_loop=n)[0]
+    assert len(long) == 4 + 1 + n
+
+
+@pytest.fixture(scope="module")
+def oracle_mod_():
+    from oracle import oracle
+    return oracle
+
+
+def test_base_full_size(hip, oracle_mod_):
+    """BASELINE config 5 model (Whisper-base, full 1500-frame context and 51 865 vocabulary): fp32 tokens vs the oracle,
+    f16 + f16 KV within 16-bit tolerance of the fp32 logits."""
+    from whisper_mojo_amd import WhisperConfig, synth
+    from whisper_mojo_amd.whisper import KVCache
+    cfg = WhisperConfig.base()
+    w = oracle_mod_.synth_weights_c(cfg, 0)
+    mel = synth.synth_mel(cfg, 1000)
+    ref = oracle_mod_.OracleModel(cfg, w)
+    enc_ref = ref.encode(mel)
+    m = make_model(cfg, w, max_batch=1)
+    enc = m.encoder.forward(mel)
+    assert np.abs(enc - enc_ref).max() < 5e-5
+    want, logits = ref.transcribe(enc_out=enc_ref, max_loop=6, ignore_eot=True, want_logits=True)
+    got = m.transcribe_batch(mel, max_loop=6, ignore_eot=True)[0]
+    s = np.sort(logits, 1)
+    margins = s[:, -1] - s[:, -2]
+    first_bad = next((i for i in range(len(got)) if got[i] != want[i]), None)
+    assert first_bad is None or margins[first_bad - 4] < 1e-3
+    h = make_model(cfg, w, compute_dtype=2, kv_dtype=2, max_batch=1)
+    cache = KVCache(h, 1)
+    h.encoder.forward(mel, cache)
+    lg = h.decoder.forward([50258, 50259, 50359, 50363], None, cache, start_pos=0)
+    assert np.abs(lg - logits[0]).max() < 0.02
+
+
+def test_one_rank_equals_two_ranks(hip, micro_cfg, micro_weights):
+    """the same global batch on 1 vs N ranks gives identical token buffers.  Ranks are emulated on one GPU:
+    each 'rank' runs its shard_range of the utterances through its own model instance, results are packed exactly as
+    dist.gather_tokens packs them."""
+    from whisper_mojo_amd import dist as wdist, synth
+    total = 7
+    mels = synth.synth_mels(micro_cfg, 0, total)
+    prompt = (1, 2, 3, 4)
+    one = make_model(micro_cfg, micro_weights, max_batch=total)
+    ref = one.transcribe_batch(mels, prompt=prompt, eot=-1, max_loop=12)
+    stride = 4 + 1 + 12
+    bufs = []
+    for r in range(2):
+        first, count = wdist.shard_range(total, r, 2)
+        mr = make_model(micro_cfg, micro_weights, max_batch=count)
+        mr.transcribe_batch(mels[first:first + count], prompt=prompt, eot=-1, max_loop=12)
+        bufs.append(wdist.pack_tokens(mr.last_tokens, mr.last_counts, stride, (total + 1) // 2)[:count])
+    got = wdist.unpack_tokens(np.concatenate(bufs))
+    assert got == ref

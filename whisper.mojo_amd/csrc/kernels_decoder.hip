@@ -41,23 +41,27 @@ void launch_dec_embed(const float* tok_emb, const float* pos_emb, const int* tok
 //   * computed as outᵀ (A-operand = weight fragment): a lane owns 4 consecutive columns of one utterance; the NW
 //     K-partials meet in LDS and wave 0 finishes (bias / GELU / residual / KV-cache append), with its epilogue operands
 //     requested before anything else so they ride the same round trip.
-template <typename TW, int KPW, bool LN>
+template <typename TW, int KPW, bool LN, int NT>
 __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
     __shared__ float s_stat[16][16][2];
-    __shared__ __attribute__((aligned(16))) f32x4 s_red[16][64];
+    __shared__ __attribute__((aligned(16))) f32x4 s_red[16][NT][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
-    int wrow = n0 + r16;
-    wrow = wrow < p.N ? wrow : p.N - 1;
+    const int n0 = blockIdx.x * (16 * NT), b0 = blockIdx.y * 16;
     int xrow = b0 + r16;
     xrow = xrow < p.B ? xrow : p.B - 1;
-    const TW* wp = (const TW*)p.W + (size_t)wrow * p.K + g * 8;
+    const TW* wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int wrow = n0 + t * 16 + r16;
+        wrow = wrow < p.N ? wrow : p.N - 1;
+        wp[t] = (const TW*)p.W + (size_t)wrow * p.K + g * 8;
+    }
     const float* xp = p.x + (size_t)xrow * p.ldx + g * 8;
 
-    // epilogue operands (wave 0)
-    const int eb = b0 + r16, en = n0 + g * 4;
-    const bool epi = w == 0 && eb < p.B;
+    // epilogue operands (wave t finishes column tile t)
+    const int eb = b0 + r16, en = n0 + (w < NT ? w : 0) * 16 + g * 4;
+    const bool epi = w < NT && eb < p.B;
     float bias4[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 res4 = f32x4{0.f, 0.f, 0.f, 0.f};
     int cache_row = 0;
@@ -69,12 +73,13 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
         if (p.residual) res4 = *reinterpret_cast<const f32x4*>(p.residual + (size_t)eb * p.ldr + en);
         if (p.kcache) cache_row = p.ctl->len;
     }
-    Frag<TW> wf[KPW];
+    Frag<TW> wf[NT][KPW];
     f32x4 xa[KPW][2], gb[LN ? KPW : 1][4];
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
         const int k = (w + nw * i) * 32;
-        wf[i] = load_frag<TW>(wp + k);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wf[t][i] = load_frag<TW>(wp[t] + k);
         xa[i][0] = *reinterpret_cast<const f32x4*>(xp + k);
         xa[i][1] = *reinterpret_cast<const f32x4*>(xp + k + 4);
         if (LN) {
@@ -116,7 +121,9 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
         const float var = (sq / (float)p.K) - (mean * mean);
         rstd = 1.0f / sqrtf(var + 1e-5f);
     }
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
         float xv[8];
@@ -132,13 +139,16 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
                 xv[4 + j] = (xv[4 + j] - mean) * rstd * gb[i][1][j] + gb[i][3][j];
             }
         }
-        acc = mma32(wf[i], make_frag<TW>(xv), acc);
+        const Frag<TW> xf = make_frag<TW>(xv);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mma32(wf[t][i], xf, acc[t]);
     }
-    s_red[w][lane] = acc;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s_red[w][t][lane] = acc[t];
     __syncthreads();
     if (epi) {
-        f32x4 v = s_red[0][lane];
-        for (int k = 1; k < nw; ++k) v += s_red[k][lane];
+        f32x4 v = s_red[0][w][lane];
+        for (int k = 1; k < nw; ++k) v += s_red[k][w][lane];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += bias4[r];
         if (p.act) {
@@ -166,13 +176,23 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
     }
 }
 template <typename TW, int KPW> static void launch_dec_linear_t(const DecLinearParams& p, int nw, hipStream_t st) {
-    const dim3 grid((p.N + 15) / 16, (p.B + 15) / 16), block(nw * 64);
-    if (p.ln_g)
-        hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, true>), grid, block, 0, st, p);
-    else
-        hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, false>), grid, block, 0, st, p);
+    // two column tiles per workgroup for the wide projections (QKV, fc1): half the workgroups, one activation
+    // fragment (and one LayerNorm) feeding two MFMAs
+    const bool wide = p.N >= 1024 && nw >= 2;
+    const dim3 grid((p.N + (wide ? 31 : 15)) / (wide ? 32 : 16), (p.B + 15) / 16), block(nw * 64);
+    if (p.ln_g) {
+        if (wide)
+            hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, true, 2>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, true, 1>), grid, block, 0, st, p);
+    } else {
+        if (wide)
+            hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, false, 2>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, false, 1>), grid, block, 0, st, p);
+    }
 }
-// K % 32 == 0 and (K/32) must factor as NW * KPW with NW <= 16, KPW <= 4 (true for every K = 128·j, j <= 16)
+// K % 32 == 0 and (K/32) must factor as NW * KPW with NW <= 16, KPW <= 4 (true for every K = 128·j, j <= 16).
 template <typename TW> void launch_dec_linear(const DecLinearParams& p, hipStream_t st) {
     const int ksteps = p.K >> 5;
     int nw = 1;
@@ -222,22 +242,34 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
         wr = wr < p.N ? wr : p.N - 1;
         wp[nb] = (const TW*)p.W + (size_t)wr * K + g * 8;
     }
-    // the embedding rows do not depend on the activations: request the first chunk before the LayerNorm staging
+    // Memory operations retire in issue order (vmcnt), so the activation rows are requested FIRST and the embedding
+    // rows right behind them: the LayerNorm staging below waits only for the (L2-resident) activations and runs while
+    // this wave's 24 KB of embedding rows are still streaming from HBM.
     Frag<TW> wf[2][CHK];
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + i * 32);
-
+    __shared__ __attribute__((aligned(16))) float s_gb[2][K];  // LN gamma / beta, fetched ahead of the embedding rows too
     {  // LN + convert -> LDS.  thread t: row t>>2 (+64 per pass), quarter t&3 of the row, float4 index q + 4*i
         for (int rbase = 0; rbase < NRB * 16; rbase += 64) {
             const int lr = rbase + (threadIdx.x >> 2), q = threadIdx.x & 3;
-            if (lr < NRB * 16) {
+            f32x4 v[KD * 8];
+            const bool mine = lr < NRB * 16;
+            if (mine) {
                 const int row = min(lr, nrows - 1);
                 const float* xr = p.x + (size_t)(row0 + row) * p.ldx;
-                f32x4 v[KD * 8];
 #pragma unroll
                 for (int i = 0; i < KD * 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * (q + 4 * i));
+            }
+            if (rbase == 0) {
+                f32x4 gbv = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int gi = threadIdx.x;  // float4 index into [gamma | beta]
+                if (gi < K / 2) gbv = *reinterpret_cast<const f32x4*>((gi < K / 4 ? p.ln_g : p.ln_b - K) + 4 * gi);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + i * 32);
+                if (gi < K / 2) *reinterpret_cast<f32x4*>(&s_gb[0][0] + 4 * gi) = gbv;
+                __syncthreads();
+            }
+            if (mine) {
                 float sm = 0.f, sq = 0.f;
 #pragma unroll
                 for (int i = 0; i < KD * 8; ++i)
@@ -256,7 +288,7 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
 #pragma unroll
                 for (int i = 0; i < KD * 8; ++i) {
                     const int k = 4 * (q + 4 * i);
-                    const f32x4 gm = *reinterpret_cast<const f32x4*>(p.ln_g + k), bt = *reinterpret_cast<const f32x4*>(p.ln_b + k);
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(&s_gb[0][k]), bt = *reinterpret_cast<const f32x4*>(&s_gb[1][k]);
                     typedef __attribute__((ext_vector_type(4))) TW t4;
                     t4 o;
 #pragma unroll
