@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmParams p) {
             if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
             if (p.act) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], p.gelu_mode);
+                for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r], p.gelu_mode);
             }
             if (p.pos) v += *reinterpret_cast<const f32x4*>(p.pos + (size_t)m * p.N + n);
             if (Rb) v += *reinterpret_cast<const f32x4*>(Rb + (size_t)m * p.ldr + n);
@@ -237,45 +237,69 @@ template <typename T, typename TO> void launch_gemm_nt(const GemmParams& p, int 
 
 // ------------------------------------------------------------------------------------------------------------
 // LayerNorm over rows of `cols` fp32 (whisper_tensor.mojo:249-285: one-pass variance E[x²]-mean², eps inside the
-// sqrt).  One wave per row, wave64 butterfly for Σx and Σx².  Writes the GEMM-operand copy (T) and/or an fp32 copy.
-template <typename T>
+// sqrt).  Half a wave per row, butterfly for Σx and Σx².  Writes the GEMM-operand copy (T) and/or an fp32 copy.
+// Half a wave per row with 16-byte loads (cols = 128·j, j <= 8): lanes 0-31 take one row, 32-63 the next.
+template <typename T, int V4 /* float4 per lane = cols/128 */>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, T* __restrict__ out_t,
-                                                             float* __restrict__ out_f, int rows, int cols, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* xr = x + (size_t)row * cols;
-    float v[16];  // cols <= 1024
+                                                             float* __restrict__ out_f, int rows, float eps) {
+    constexpr int cols = V4 * 128;
+    const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
+    const bool ok = row < rows;
+    const float* xr = x + (size_t)(ok ? row : rows - 1) * cols;
+    f32x4 v[V4];
     float s = 0.f, q = 0.f;
-    const int n = cols >> 6;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (i < n) {
-            v[i] = xr[lane + 64 * i];
-            s += v[i];
-            q += v[i] * v[i];
+    for (int i = 0; i < V4; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * (l32 + 32 * i));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s += v[i][j];
+            q += v[i][j] * v[i][j];
         }
-    s = wave_sum(s);
-    q = wave_sum(q);
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {  // stays inside the 32-lane half
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
     const float mean = s / (float)cols;
     const float var = (q / (float)cols) - (mean * mean);
     const float inv_std = 1.0f / sqrtf(var + eps);
+    if (!ok) return;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (i < n) {
-            const int c = lane + 64 * i;
-            float y = (v[i] - mean) * inv_std * gamma[c] + beta[c];
-            if (out_t) out_t[(size_t)row * cols + c] = from_f32<T>(y);
-            if (out_f) out_f[(size_t)row * cols + c] = y;
+    for (int i = 0; i < V4; ++i) {
+        const int c = 4 * (l32 + 32 * i);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * inv_std * gm[j] + bt[j];
+        if (out_t) {
+            typedef __attribute__((ext_vector_type(4))) T t4;
+            t4 o = {from_f32<T>(y[0]), from_f32<T>(y[1]), from_f32<T>(y[2]), from_f32<T>(y[3])};
+            *reinterpret_cast<t4*>(out_t + (size_t)row * cols + c) = o;
         }
+        if (out_f) *reinterpret_cast<f32x4*>(out_f + (size_t)row * cols + c) = y;
+    }
 }
 
 template <typename T>
 void launch_layernorm_rows(const float* x, const float* gamma, const float* beta, void* out_t, float* out_f, int rows,
                            int cols, float eps, hipStream_t st) {
-    hipLaunchKernelGGL(layernorm_rows_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, st, x, gamma, beta, (T*)out_t, out_f,
-                       rows, cols, eps);
+    const dim3 grid((rows + 7) / 8), block(256);
+#define WM_LN(V4) hipLaunchKernelGGL((layernorm_rows_kernel<T, V4>), grid, block, 0, st, x, gamma, beta, (T*)out_t, out_f, rows, eps)
+    switch (cols / 128) {
+        case 1: WM_LN(1); break;
+        case 2: WM_LN(2); break;
+        case 3: WM_LN(3); break;
+        case 4: WM_LN(4); break;
+        case 5: WM_LN(5); break;
+        case 6: WM_LN(6); break;
+        case 7: WM_LN(7); break;
+        default: WM_LN(8); break;
+    }
+#undef WM_LN
 }
 
 // ------------------------------------------------------------------------------------------------------------
