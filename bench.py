@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--workload", default="tiny_b64_bf16", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after another")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2, 3, 4], help="steps in flight (library pipeline slots)")
     args = ap.parse_args()
 
     import torch
@@ -131,9 +133,28 @@ def main():
     mel_dev = torch.from_numpy(mel_host).to(dev)  # resident in HBM before the timed region
     stride = 4 + 1 + DECODE_STEPS
 
-    def step():
-        model.transcribe_batch(mel_dev, max_loop=DECODE_STEPS, ignore_eot=True)
-        return wdist.gather_tokens(model.last_tokens, model.last_counts, total, stride)
+    # Steps are issued through the library's pipeline slots (wm_transcribe_submit / _wait): step k+1 is submitted
+    # before step k's ids are collected, so its MFMA-bound encoder overlaps step k's latency/HBM-bound decode, and the
+    # token all-gather of step k overlaps step k+1 entirely.  Every step still does the full work; all K steps are
+    # complete (ids on the host, gathered) before the timed region closes.  --no-pipeline runs them one after another.
+    def run_steps(n):
+        out = None
+        if args.no_pipeline:
+            for _ in range(n):
+                model.transcribe_batch(mel_dev, max_loop=DECODE_STEPS, ignore_eot=True)
+                out = wdist.gather_tokens(model.last_tokens, model.last_counts, total, stride)
+            return out
+        depth, inflight = args.pipeline, []
+        for k in range(n):
+            if len(inflight) == depth:  # oldest step: collect its ids (+ all-gather) before its slot is reused
+                model.transcribe_wait(inflight.pop(0))
+                out = wdist.gather_tokens(model.last_tokens, model.last_counts, total, stride)
+            model.transcribe_submit(mel_dev, slot=k % depth, max_loop=DECODE_STEPS, ignore_eot=True)
+            inflight.append(k % depth)
+        while inflight:
+            model.transcribe_wait(inflight.pop(0))
+            out = wdist.gather_tokens(model.last_tokens, model.last_counts, total, stride)
+        return out
 
     def sync():
         torch.cuda.synchronize()
@@ -142,22 +163,35 @@ def main():
             torch.cuda.synchronize()
 
     log("model loaded, mels resident; warm-up")
-    for _ in range(args.warmup):
-        out = step()
+    out = run_steps(args.warmup)
     sync()
     log("timed region")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    out = run_steps(args.steps)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    assert len(out) == total and all(len(o) == stride for o in out)
+    assert out is not None and len(out) == total and all(len(o) == stride for o in out)
 
     log(f"timed region done: {dt:.3f} s")
+    # the same K steps strictly one after another (no overlap between steps), for reference
+    seq_dt = None
+    if not args.no_pipeline and args.pipeline > 1:
+        saved, args.no_pipeline = args.no_pipeline, True
+        run_steps(1)
+        sync()
+        t1 = time.perf_counter()
+        run_steps(args.steps)
+        sync()
+        seq_dt = time.perf_counter() - t1
+        args.no_pipeline = saved
+        if world > 1:
+            t = torch.tensor([seq_dt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            seq_dt = float(t.item())
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         rtf = total * CLIP_SECONDS * args.steps / dt
@@ -186,9 +220,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cdt, "data": "synthetic",
             "tokens_per_sec": round(tok_s, 1),
+            "unpipelined": None if seq_dt is None else {"ms_per_step": round(seq_dt / args.steps * 1e3, 3),
+                                                        "value": round(total * CLIP_SECONDS * args.steps / seq_dt, 1)},
             "config": {"workload": f"whisper-{cfg_name}, {B} synthetic 80x3000 mels per GPU ({total} total), greedy, 1 prefill + "
                                    f"{DECODE_STEPS} decode steps, operands {cdt}, KV cache {kdt}, random-init weights (seed 0)",
-                       "name": args.workload, "utterances_per_gpu": B, "kv_dtype": kdt, "parallelism": f"dp{world}"},
+                       "name": args.workload, "utterances_per_gpu": B, "kv_dtype": kdt, "parallelism": f"dp{world}",
+                       "pipeline_depth": 1 if args.no_pipeline else args.pipeline},
             "roofline": {"bound": "hbm", "kernel": "attn_decode_kernel (decoder cross-attention, one layer, all utterances)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.workload),
@@ -197,7 +234,7 @@ def main():
                             "GBps": round(step_gbs, 1), "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
             "encoder": {"ms": round(enc_us.value / 1e3, 3), "TFLOPs": round(enc_flops / (enc_us.value * 1e-6) / 1e12, 1)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             log("cpu baseline (oracle) ...")
             res["cpu_baseline"] = cpu_baseline(cfg, weights, mel_host[0], DECODE_STEPS)
         print(json.dumps(res), flush=True)

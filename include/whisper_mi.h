@@ -92,12 +92,21 @@ int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, int q_len, c
 int wm_transcribe(wm_model* m, const float* mel, int mel_on_device, int B, const wm_decode_opts* opts,
                   int32_t* tokens_out, int32_t* n_tokens);
 
+/* Pipelined form for back-to-back batches (serving / bench): wm_transcribe_submit enqueues the encoder (model stream) and
+ * the whole greedy loop (the slot's decode stream) and returns immediately; wm_transcribe_wait blocks until that slot's
+ * ids are ready and copies them out (same layout as wm_transcribe).  Four slots (0..3): submitting batch i+1 before
+ * waiting for batch i overlaps its MFMA-bound encoder with batch i's latency/HBM-bound decode.  In this form every
+ * max_loop step is enqueued (no early exit); finished utterances simply stop recording, so the ids are identical to
+ * wm_transcribe's.  mel must stay valid until the matching wait when it is a device pointer. */
+int wm_transcribe_submit(wm_model* m, int slot, const float* mel, int mel_on_device, int B, const wm_decode_opts* opts);
+int wm_transcribe_wait(wm_model* m, int slot, int32_t* tokens_out, int32_t* n_tokens);
+
 /* ---- op-level entry points (host pointers; known-answer tests only) ------------------------------------------
  * Same argument meaning as the reference ops: out-param first, caller-allocated. */
 /* matmul(C, A, B, bias)  whisper_tensor.mojo:151-246 : C[M,N] = A[M,K]·B[N,K]ᵀ (+bias[N], may be NULL).
  * dtype selects the operand rounding (WM_F32 exact).  Requires K % 32 == 0. */
 int wm_op_matmul_nt(float* C, const float* A, const float* B, const float* bias, int M, int N, int K, int dtype);
-/* layer_norm(out, inp, gamma, beta, eps)  whisper_tensor.mojo:249-285 (one-pass variance). cols % 64 == 0 */
+/* layer_norm(out, inp, gamma, beta, eps)  whisper_tensor.mojo:249-285 (one-pass variance). cols % 128 == 0, <= 1024 */
 int wm_op_layer_norm(float* out, const float* inp, const float* gamma, const float* beta, int rows, int cols,
                      float eps);
 /* gelu(t) in place  whisper_tensor.mojo:288-308 (mode WM_GELU_TANH) */

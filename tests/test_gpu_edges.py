@@ -110,3 +110,32 @@ def test_one_rank_equals_two_ranks(hip, micro_cfg, micro_weights):
         bufs.append(wdist.pack_tokens(mr.last_tokens, mr.last_counts, stride, (total + 1) // 2)[:count])
     got = wdist.unpack_tokens(np.concatenate(bufs))
     assert got == ref
+
+
+def test_pipelined_submit_wait_equals_synchronous(hip, micro_cfg, micro_weights):
+    """wm_transcribe_submit / _wait on the two pipeline slots give exactly wm_transcribe's ids, in any interleaving, also in
+    the eot-stopping mode (where the pipelined form enqueues all steps and finished utterances stop recording)."""
+    from whisper_mojo_amd import _lib, synth
+    m = make_model(micro_cfg, micro_weights, max_batch=3)
+    a, b = synth.synth_mels(micro_cfg, 0, 3), synth.synth_mels(micro_cfg, 10, 3)
+    kw = dict(prompt=(1, 2, 3, 4), eot=-1, max_loop=15)
+    ra, rb = m.transcribe_batch(a, **kw), m.transcribe_batch(b, **kw)
+    m.transcribe_submit(a, slot=0, **kw)
+    m.transcribe_submit(b, slot=1, **kw)
+    assert m.transcribe_wait(0) == ra
+    m.transcribe_submit(a, slot=0, **kw)   # slot 0 reused while slot 1 is still in flight
+    assert m.transcribe_wait(1) == rb
+    assert m.transcribe_wait(0) == ra
+    eot = ra[0][7]
+    kw2 = dict(prompt=(1, 2, 3, 4), eot=eot, max_loop=15)
+    want = m.transcribe_batch(a, **kw2)
+    m.transcribe_submit(a, slot=1, **kw2)
+    assert m.transcribe_wait(1) == want
+    m.transcribe_submit(a, slot=0, **kw)
+    with pytest.raises(_lib.WhisperMiError, match="not waited"):
+        m.transcribe_submit(b, slot=0, **kw)
+    m.transcribe_wait(0)
+    with pytest.raises(_lib.WhisperMiError, match="nothing was submitted"):
+        _lib.check(_lib.lib().wm_transcribe_wait(m._h, 0, None, None) if False else _lib.lib().wm_transcribe_wait(
+            m._h, 0, np.zeros(4, np.int32).ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_int32)),
+            np.zeros(4, np.int32).ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_int32))))

@@ -9,4 +9,5 @@ for line in sys.stdin:
     r, ds, e = d["roofline"], d["decode_step"], d["encoder"]
     print(f"{d['config']['name']}: RTF {d['value']:.0f}  {d['ms_per_step']:.2f} ms/pass  tok/s {d['tokens_per_sec']:.0f} | cross-attn {r['us_per_launch']} us "
           f"{r['achieved']} GB/s ({r['frac']:.3f}) | step(1 lane) {ds['us']} us {ds['GBps']} GB/s | enc {e['ms']} ms {e['TFLOPs']} TF"
+          + (f" | unpipelined {d['unpipelined']['ms_per_step']} ms" if d.get("unpipelined") else "")
           + (f" | cpu RTF {d['cpu_baseline']['value']} ({d['cpu_baseline']['cores']} thr)" if "cpu_baseline" in d else ""))

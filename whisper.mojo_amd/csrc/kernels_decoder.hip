@@ -725,6 +725,23 @@ void launch_argmax_plain(const float* t, int n, int* idx, hipStream_t st) {
     hipLaunchKernelGGL(argmax_plain_kernel, dim3(1), dim3(1024), 0, st, t, n, idx);
 }
 
+// start of a greedy run: tokens = prompt (whisper.mojo:187-191, 200-202), nothing finished, control block zeroed
+__global__ void init_tokens_kernel(InitTokensParams p) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < p.B) {
+        for (int i = 0; i < p.n_prompt; ++i) p.out_tokens[(size_t)b * p.out_stride + i] = p.prompt[i];
+        p.n_tokens[b] = p.n_prompt;
+        p.finished[b] = 0;
+    }
+    if (b == 0) {
+        p.ctl->len = 0;
+        p.ctl->n_finished = 0;
+    }
+}
+void launch_init_tokens(const InitTokensParams& p, hipStream_t st) {
+    hipLaunchKernelGGL(init_tokens_kernel, dim3((p.B + 255) / 256), dim3(256), 0, st, p);
+}
+
 // current_len += 1 (layers.mojo:143) and every utterance's position += 1
 __global__ void advance_kernel(StepCtl* ctl, int* pos, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -122,7 +122,9 @@ struct wm_model {
     std::vector<DecLayer> dec;
     DevBuf dec_ln_g, dec_ln_b;
     DevBuf cross_kv_w, cross_kv_b;  // [L*2*d][d] rows: layer-major, K then V
-    wm_state* cached = nullptr;
+    static const int NSLOT = 4;
+    wm_state* cached = nullptr;           // slot 0: the state behind wm_transcribe / wm_transcribe_submit(slot 0)
+    wm_state* slots[3] = {nullptr, nullptr, nullptr};  // slots 1..3: further pipeline stages (wm_transcribe_submit)
 };
 
 struct wm_state {
@@ -148,6 +150,8 @@ struct wm_state {
     StepCtl* h_ctl = nullptr;  // pinned host copy of the control blocks (finish polling)
     int graph_eot = 0, graph_ignore = 0;
     bool graphs_valid = false;
+    bool pending = false;   // a submitted pass has not been waited for yet
+    int pend_total = 0;     // ids per utterance of the pending pass
     const float* last_mel = nullptr;  // device pointer of the last encoded batch (bench replays the encoder on it)
     // encoder arena (sized for Bc utterances)
     DevBuf mel_dev, mel_t, h1, x, xn, qkv, ao, hid, enc_t;
@@ -252,6 +256,8 @@ extern "C" void wm_model_free(wm_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->cached) wm_state_free(m->cached);
+    for (auto& sl : m->slots)
+        if (sl) wm_state_free(sl);
     DevBuf* top[] = {&m->conv1_w, &m->conv1_b, &m->conv2_w, &m->conv2_b, &m->enc_pos, &m->enc_ln_g, &m->enc_ln_b,
                      &m->tok_emb_f, &m->tok_emb_t, &m->dec_pos, &m->dec_ln_g, &m->dec_ln_b, &m->cross_kv_w, &m->cross_kv_b};
     for (DevBuf* b : top) b->release();
@@ -960,26 +966,31 @@ extern "C" int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, i
 }
 
 // ---- Whisper.transcribe: whisper.mojo:184-223 ------------------------------------------------------------------------
-static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o) {
+// Enqueues the whole greedy loop for state s on its decode lane streams; returns without waiting.  The lanes first wait
+// for the encoder (recorded on the model stream).  allow_poll: the synchronous entry point may stop early when every
+// utterance has emitted eot; the pipelined one enqueues all max_loop steps (finished utterances stop recording).
+static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, bool allow_poll) {
     const int B = s->B;
-    hipStream_t st0 = m->stream;
-    // tokens = prompt (whisper.mojo:187-191, 200-202)
-    std::vector<int32_t> rows((size_t)B * s->out_stride, 0), nt(B, o->n_prompt);
-    for (int b = 0; b < B; ++b)
-        for (int i = 0; i < o->n_prompt; ++i) rows[(size_t)b * s->out_stride + i] = o->prompt[i];
-    HIPCHK(hipMemcpyAsync(s->out_tokens.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st0));
-    HIPCHK(hipMemcpyAsync(s->n_tokens.p, nt.data(), B * 4, hipMemcpyHostToDevice, st0));
-    HIPCHK(hipMemsetAsync(s->finished.p, 0, B * 4, st0));
-    HIPCHK(hipMemsetAsync(s->ctl.p, 0, s->ctl.bytes, st0));
-    HIPCHK(hipStreamSynchronize(st0));  // rows / nt are pageable host memory; also: encoder + cross K/V complete
+    HIPCHK(hipEventRecord(s->enc_done, m->stream));  // encoder + cross K/V of this state
     static const bool trace_phase = getenv("WM_TRACE_HOST") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
-
     static const bool no_graph = getenv("WM_NO_GRAPH") != nullptr;
     const bool recapture = !s->graphs_valid || s->graph_eot != o->eot || s->graph_ignore != o->ignore_eot;
     const int first_pos = o->pos_mode == WM_POS_REF ? o->n_prompt - 1 : o->n_prompt;
+    InitTokensParams ip{};
+    ip.n_prompt = o->n_prompt;
+    for (int i = 0; i < o->n_prompt; ++i) ip.prompt[i] = o->prompt[i];
     for (auto& ln : s->lanes) {
         const DecView v{ln.b0, ln.nb, ln.st, ln.ctl};
+        HIPCHK(hipStreamWaitEvent(v.st, s->enc_done, 0));
+        // tokens = prompt (whisper.mojo:187-191, 200-202); finished = 0; control block = 0
+        ip.out_tokens = s->out_tokens.as<int>() + (size_t)v.b0 * s->out_stride;
+        ip.out_stride = s->out_stride;
+        ip.n_tokens = s->n_tokens.as<int>() + v.b0;
+        ip.finished = s->finished.as<int>() + v.b0;
+        ip.ctl = v.ctl;
+        ip.B = v.nb;
+        launch_init_tokens(ip, v.st);
         // prefill (whisper.mojo:195, start_pos=0): the q_len = n_prompt causal block equals n_prompt single-token steps
         for (int i = 0; i < o->n_prompt; ++i) {
             launch_set_step(v.ctl, i, 1, s->pos.as<int>() + v.b0, i, s->tok.as<int>() + v.b0, o->prompt[i], v.nb, v.st);
@@ -1000,8 +1011,6 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o) 
             decode_core(m, s, v, true);
             launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, true), v.st);
             HIPCHK(hipStreamEndCapture(v.st, &g));
-            // hipGraphLaunch (ROCm 7.2) blocks the host while the previous launch of the SAME exec is in flight, so the
-            // step is instantiated NEXEC times and the instances are launched round-robin: the host runs ahead again
             hipError_t ge = hipSuccess;
             for (int k = 0; k < wm_state::Lane::NEXEC && ge == hipSuccess; ++k) ge = hipGraphInstantiate(&ln.graph[k], g, nullptr, nullptr, 0);
             (void)hipGraphDestroy(g);
@@ -1011,17 +1020,15 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o) 
     s->graphs_valid = !no_graph;
     s->graph_eot = o->eot;
     s->graph_ignore = o->ignore_eot;
-
     if (trace_phase) {
         for (auto& ln : s->lanes) (void)hipStreamSynchronize(ln.st);
-        fprintf(stderr, "[wm] prefill (+graph capture if any): %.3f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count() * 1e3);
+        fprintf(stderr, "[wm] encoder wait + prefill (+graph capture if any): %.3f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count() * 1e3);
     }
     StepCtl* h_ctl = s->h_ctl;
     int rc = 0;
-    static const bool trace_host = getenv("WM_TRACE_HOST") != nullptr;
     const auto t_loop0 = std::chrono::steady_clock::now();
     for (int it = 0; it < o->max_loop && !rc; ++it) {
-        if (!o->ignore_eot && (it % 8) == 0) {  // "if next_token == eot: break", for the whole batch
+        if (allow_poll && !o->ignore_eot && (it % 8) == 0) {  // "if next_token == eot: break", for the whole batch
             int fin = 0;
             for (auto& ln : s->lanes) {
                 hipError_t e = hipMemcpyAsync(h_ctl, ln.ctl, sizeof(StepCtl), hipMemcpyDeviceToHost, ln.st);
@@ -1034,7 +1041,7 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o) 
             }
             if (rc || fin >= B) break;
         }
-        for (auto& ln : s->lanes) {  // lanes are independent: launches interleave, the GPU overlaps them
+        for (auto& ln : s->lanes) {
             if (ln.graph[0] && !no_graph) {
                 hipError_t e = hipGraphLaunch(ln.graph[it % wm_state::Lane::NEXEC], ln.st);
                 if (e != hipSuccess) {
@@ -1049,7 +1056,7 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o) 
         }
     }
     if (rc) return rc;
-    if (trace_host) {
+    if (trace_phase) {
         const auto t1 = std::chrono::steady_clock::now();
         for (auto& ln : s->lanes) (void)hipStreamSynchronize(ln.st);
         const auto t2 = std::chrono::steady_clock::now();
@@ -1057,31 +1064,33 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o) 
                 s->lanes.size(), std::chrono::duration<double>(t1 - t_loop0).count() * 1e6 / std::max(1, o->max_loop),
                 std::chrono::duration<double>(t2 - t1).count() * 1e3);
     }
-    for (auto& ln : s->lanes) {  // join: the main stream continues after every lane
-        HIPCHK(hipEventRecord(ln.done, ln.st));
-        HIPCHK(hipStreamWaitEvent(st0, ln.done, 0));
-    }
+    for (auto& ln : s->lanes) HIPCHK(hipEventRecord(ln.done, ln.st));
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-extern "C" int wm_transcribe(wm_model* m, const float* mel, int mel_on_device, int B, const wm_decode_opts* o,
-                             int32_t* tokens_out, int32_t* n_tokens) {
-    if (!m || !mel || !o || !tokens_out || !n_tokens || B <= 0) return fail(WM_E_ARG, "bad argument");
-    if (!o->prompt || o->n_prompt <= 0 || o->max_loop < 0) return fail(WM_E_ARG, "bad decode options");
+static int check_opts(wm_model* m, const wm_decode_opts* o, int B) {
+    if (!o || B <= 0) return fail(WM_E_ARG, "bad argument");
+    if (!o->prompt || o->n_prompt <= 0 || o->n_prompt > 16 || o->max_loop < 0) return fail(WM_E_ARG, "bad decode options (1 <= n_prompt <= 16)");
     const wm_dims& c = m->cfg.dims;
     const int total = o->n_prompt + 1 + o->max_loop;
     if (total > c.n_text_ctx + 1 || total > OUT_STRIDE_MAX)
         return fail(WM_E_ARG, "n_prompt + 1 + max_loop = %d exceeds the decoder context %d", total, c.n_text_ctx);
     for (int i = 0; i < o->n_prompt; ++i)
         if (o->prompt[i] < 0 || o->prompt[i] >= c.vocab) return fail(WM_E_ARG, "prompt id out of range");
+    return 0;
+}
+
+static int submit_on(wm_model* m, wm_state** slot, const float* mel, int mel_on_device, int B, const wm_decode_opts* o, bool allow_poll) {
+    const wm_dims& c = m->cfg.dims;
     HIPCHK(hipSetDevice(m->device));
-    if (!m->cached || m->cached->B != B) {
-        if (m->cached) wm_state_free(m->cached);
-        m->cached = nullptr;
-        WMCHK(wm_state_new(m, B, &m->cached));
+    if (!*slot || (*slot)->B != B) {
+        if (*slot) wm_state_free(*slot);
+        *slot = nullptr;
+        WMCHK(wm_state_new(m, B, slot));
     }
-    wm_state* s = m->cached;
+    wm_state* s = *slot;
+    if (s->pending) return fail(WM_E_STATE, "this slot still holds a pass that was not waited for");
     WMCHK(wm_state_reset(s));
     const float* mel_dev = mel;
     if (!mel_on_device) {
@@ -1091,17 +1100,51 @@ extern "C" int wm_transcribe(wm_model* m, const float* mel, int mel_on_device, i
     const auto tt0 = std::chrono::steady_clock::now();
     WMCHK(run_encoder(m, s, mel_dev, B));
     s->has_enc = s->has_cross = true;
+    s->last_mel = mel_dev;
     if (getenv("WM_TRACE_HOST")) {
         const auto tt1 = std::chrono::steady_clock::now();
         (void)hipStreamSynchronize(m->stream);
         fprintf(stderr, "[wm] encoder: enqueue %.3f ms, done after %.3f ms\n", std::chrono::duration<double>(tt1 - tt0).count() * 1e3,
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - tt0).count() * 1e3);
     }
-    WMCHK(transcribe_decode(m, s, o));
-    HIPCHK(hipMemcpy2DAsync(tokens_out, (size_t)total * 4, s->out_tokens.p, (size_t)s->out_stride * 4, (size_t)total * 4, B, hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipMemcpyAsync(n_tokens, s->n_tokens.p, B * 4, hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipStreamSynchronize(m->stream));
+    WMCHK(transcribe_decode(m, s, o, allow_poll));
+    s->pending = true;
+    s->pend_total = o->n_prompt + 1 + o->max_loop;
+    s->host_len = 0;
     return 0;
+}
+
+static int wait_on(wm_model* m, wm_state* s, int32_t* tokens_out, int32_t* n_tokens) {
+    if (!s || !s->pending) return fail(WM_E_STATE, "nothing was submitted on this slot");
+    HIPCHK(hipSetDevice(m->device));
+    for (auto& ln : s->lanes) HIPCHK(hipEventSynchronize(ln.done));
+    const int total = s->pend_total;
+    HIPCHK(hipMemcpy2D(tokens_out, (size_t)total * 4, s->out_tokens.p, (size_t)s->out_stride * 4, (size_t)total * 4, s->B, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(n_tokens, s->n_tokens.p, (size_t)s->B * 4, hipMemcpyDeviceToHost));
+    s->pending = false;
+    s->has_enc = false;  // the KV cache now holds a finished decode: a new wm_encode is needed before wm_decode_step
+    return 0;
+}
+
+extern "C" int wm_transcribe(wm_model* m, const float* mel, int mel_on_device, int B, const wm_decode_opts* o,
+                             int32_t* tokens_out, int32_t* n_tokens) {
+    if (!m || !mel || !tokens_out || !n_tokens) return fail(WM_E_ARG, "bad argument");
+    WMCHK(check_opts(m, o, B));
+    WMCHK(submit_on(m, &m->cached, mel, mel_on_device, B, o, true));
+    return wait_on(m, m->cached, tokens_out, n_tokens);
+}
+
+// Pipelined form of Whisper.transcribe for back-to-back batches: submit enqueues encoder (model stream) and the greedy
+// loop (the slot's decode stream) and returns; wait blocks until that slot's tokens are ready.  With two slots the
+// MFMA-bound encoder of batch i+1 overlaps the latency/HBM-bound decode of batch i.
+extern "C" int wm_transcribe_submit(wm_model* m, int slot, const float* mel, int mel_on_device, int B, const wm_decode_opts* o) {
+    if (!m || !mel || slot < 0 || slot >= wm_model::NSLOT) return fail(WM_E_ARG, "bad argument (slot must be 0..3)");
+    WMCHK(check_opts(m, o, B));
+    return submit_on(m, slot == 0 ? &m->cached : &m->slots[slot - 1], mel, mel_on_device, B, o, false);
+}
+extern "C" int wm_transcribe_wait(wm_model* m, int slot, int32_t* tokens_out, int32_t* n_tokens) {
+    if (!m || !tokens_out || !n_tokens || slot < 0 || slot >= wm_model::NSLOT) return fail(WM_E_ARG, "bad argument");
+    return wait_on(m, slot == 0 ? m->cached : m->slots[slot - 1], tokens_out, n_tokens);
 }
 
 // ---- measurement helpers ------------------------------------------------------------------------------------------------

@@ -103,6 +103,16 @@ struct ArgmaxParams {
     int* pos;
 };
 void launch_argmax_step(const ArgmaxParams& p, hipStream_t st);
+struct InitTokensParams {
+    int* out_tokens;
+    int out_stride;
+    int* n_tokens;
+    int* finished;
+    StepCtl* ctl;
+    int B, n_prompt;
+    int prompt[16];
+};
+void launch_init_tokens(const InitTokensParams& p, hipStream_t st);
 void launch_advance(StepCtl* ctl, int* pos, int B, hipStream_t st);
 void launch_set_step(StepCtl* ctl, int len, int set_len, int* pos, int pos_value, int* tok, int tok_value, int B,
                      hipStream_t st);

@@ -183,6 +183,28 @@ class Whisper:
         self.last_tokens, self.last_counts = toks, n
         return [toks[b, :n[b]].tolist() for b in range(B)]
 
+    def transcribe_submit(self, mel, slot: int = 0, prompt: Sequence[int] = PROMPT, eot: int = EOT, max_loop: int = MAX_LOOP,
+                          ignore_eot: bool = False):
+        """Pipelined form (wm_transcribe_submit): enqueue encoder + greedy loop for this batch on pipeline slot 0/1 and
+        return at once; `transcribe_wait(slot)` collects the ids.  Submitting batch i+1 before waiting for batch i lets
+        its encoder overlap batch i's decode."""
+        if self._h is None:
+            raise _lib.WhisperMiError("model not loaded")
+        ptr, on_dev, B, keep = _mel_arg(mel, self.config)
+        p = np.asarray(prompt, np.int32)
+        opts = _lib.WmDecodeOpts(_ip(p), len(p), eot, max_loop, self.pos_mode, int(ignore_eot))
+        _lib.check(_lib.lib().wm_transcribe_submit(self._h, slot, ptr, on_dev, B, C.byref(opts)))
+        self._pending = getattr(self, "_pending", {})
+        self._pending[slot] = (B, len(p) + 1 + max_loop, keep)
+
+    def transcribe_wait(self, slot: int = 0) -> List[List[int]]:
+        B, total, _keep = self._pending.pop(slot)
+        toks = np.zeros((B, total), np.int32)
+        n = np.zeros(B, np.int32)
+        _lib.check(_lib.lib().wm_transcribe_wait(self._h, slot, _ip(toks), _ip(n)))
+        self.last_tokens, self.last_counts = toks, n
+        return [toks[b, :n[b]].tolist() for b in range(B)]
+
     def transcribe(self, mel) -> List[int]:
         """whisper.mojo:184-223: mel [80, 3000] -> token ids."""
         return self.transcribe_batch(mel)[0]
