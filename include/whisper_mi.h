@@ -101,6 +101,16 @@ int wm_transcribe(wm_model* m, const float* mel, int mel_on_device, int B, const
 int wm_transcribe_submit(wm_model* m, int slot, const float* mel, int mel_on_device, int B, const wm_decode_opts* opts);
 int wm_transcribe_wait(wm_model* m, int slot, int32_t* tokens_out, int32_t* n_tokens);
 
+/* ---- log-mel front end --------------------------------------------------------------------------
+ * Replaces the reference's call to HF WhisperProcessor (export_weights.py:100-116): 16 kHz mono PCM -> pad / trim to the
+ * 30 s window -> 400-point Hann STFT (hop 160, reflect padding) -> 80 slaney mel bands -> log10 -> clamp to max-8 ->
+ * (x+4)/4.  pcm: host [B, stride] fp32, n_samples[b] <= stride valid samples each.  mel_out: NULL or host
+ * [B, n_mels, 2*n_audio_ctx] (the sample_input.bin layout the encoder takes). */
+int wm_log_mel(wm_model* m, const float* pcm, const int32_t* n_samples, int B, int stride, float* mel_out);
+/* PCM in, token ids out: front end + wm_transcribe without the mel ever leaving the GPU. */
+int wm_transcribe_pcm(wm_model* m, const float* pcm, const int32_t* n_samples, int B, int stride, const wm_decode_opts* opts,
+                      int32_t* tokens_out, int32_t* n_tokens);
+
 /* ---- op-level entry points (host pointers; known-answer tests only) ------------------------------------------
  * Same argument meaning as the reference ops: out-param first, caller-allocated. */
 /* matmul(C, A, B, bias)  whisper_tensor.mojo:151-246 : C[M,N] = A[M,K]·B[N,K]ᵀ (+bias[N], may be NULL).

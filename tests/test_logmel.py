@@ -1,0 +1,85 @@
+"""Log-mel front end.  CPU: the numpy restatement vs the fixture generated from the transformers
+WhisperFeatureExtractor the reference delegates to (export_weights.py:100-116).  GPU: the HIP front end vs both.
+Tolerance on the normalised log-mel (range about [-1, 1.1]): the reference pipeline runs the FFT in float64; the GPU runs
+an exact-fp32 MFMA DFT, so bins far below a frame's peak carry fp32 round-off — 2e-3 absolute, 1e-4 on the mean."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+
+def _cases():
+    from oracle import logmel_oracle as lo
+    g = golden("logmel")
+    for i in range(4):
+        audio = lo.synth_audio(int(g[f"seed{i}"]), int(g[f"n{i}"]))
+        yield i, audio, g
+
+
+def test_oracle_matches_hf_fixture():
+    from oracle import logmel_oracle as lo
+    g = golden("logmel")
+    fb = lo.mel_filter_bank()
+    assert np.abs(fb.sum(0) - g["mel_filters_colsum"]).max() < 1e-6
+    assert np.abs(fb[::10, ::8] - g["mel_filters_sample"]).max() < 1e-7
+    for i, audio, g in _cases():
+        mel = lo.log_mel(audio)
+        assert mel.shape == (80, 3000) and mel.dtype == np.float32
+        assert np.abs(mel[:, g["cols"]] - g[f"mel{i}_cols"]).max() < 5e-5
+        assert np.abs(mel.astype(np.float64).sum(1) - g[f"mel{i}_rowsum"]).max() < 5e-2
+        assert np.abs(mel.astype(np.float64).sum(0) - g[f"mel{i}_colsum"]).max() < 2e-3
+
+
+def test_synth_audio_is_reproducible():
+    from oracle import logmel_oracle as lo
+    a = lo.synth_audio(5, 20000)
+    assert a.dtype == np.float32 and np.array_equal(a, lo.synth_audio(5, 20000)) and not np.array_equal(a, lo.synth_audio(6, 20000))
+    assert np.abs(a).max() < 1.0
+    assert np.allclose(np.abs(a[8000:12000]), 0.02)  # third 0.25 s segment: no noise, only the square tone
+    assert (a[12000:16000] != 0).any() and np.abs(a[4000:8000]).max() < np.abs(a[0:4000]).max()
+
+
+@pytest.mark.gpu
+def test_gpu_front_end_matches_oracle_and_fixture(tiny_cfg, tiny_weights):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import logmel_oracle as lo
+    from whisper_mojo_amd import frontend
+    from whisper_mojo_amd.loader import WeightLoader
+    from whisper_mojo_amd.whisper import Whisper
+    m = Whisper(tiny_cfg, max_batch=4)
+    m.load(WeightLoader.from_array(tiny_weights))
+    audios = [a for _, a, _ in _cases()]
+    g = golden("logmel")
+    mels = frontend.log_mel(m, audios)  # one ragged batch: full, short, over-long, tiny
+    assert mels.shape == (4, 80, 3000)
+    for i, a in enumerate(audios):
+        ref = lo.log_mel(a)
+        err = np.abs(mels[i] - ref)
+        assert err.max() < 2e-3 and err.mean() < 1e-4, (i, err.max(), err.mean())
+        assert np.abs(mels[i][:, g["cols"]] - g[f"mel{i}_cols"]).max() < 2e-3
+        assert np.array_equal(frontend.log_mel(m, [a])[0], mels[i])  # batch invariance
+    # PCM -> tokens == mel -> tokens
+    want = m.transcribe_batch(mels[:2], max_loop=8, ignore_eot=True)
+    got = frontend.transcribe_audio(m, audios[:2], max_loop=8, ignore_eot=True)
+    assert got == want
+
+
+@pytest.mark.gpu
+def test_gpu_front_end_micro_config(micro_cfg, micro_weights):
+    """Other window lengths / mel counts (micro: 16 mels, 200 frames = 2 s)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import logmel_oracle as lo
+    from whisper_mojo_amd import frontend
+    from whisper_mojo_amd.loader import WeightLoader
+    from whisper_mojo_amd.whisper import Whisper
+    m = Whisper(micro_cfg, max_batch=2)
+    m.load(WeightLoader.from_array(micro_weights))
+    audios = [lo.synth_audio(9, 32000), lo.synth_audio(10, 5000)]
+    mels = frontend.log_mel(m, audios)
+    for i, a in enumerate(audios):
+        ref = lo.log_mel(a, n_frames=micro_cfg.n_frames, n_mels=micro_cfg.n_mels)
+        assert np.abs(mels[i] - ref).max() < 2e-3

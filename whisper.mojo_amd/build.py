@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libwhispermi.so")
-SOURCES = ["whisper_mi.cpp", "kernels_encoder.hip", "kernels_decoder.hip"]
+SOURCES = ["whisper_mi.cpp", "kernels_encoder.hip", "kernels_decoder.hip", "kernels_frontend.hip"]
 HEADERS = ["wm_device.h", "wm_kernels.h", "../../include/whisper_mi.h", "../../include/wm_synth.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-ffp-contract=on"]

@@ -122,6 +122,12 @@ struct wm_model {
     std::vector<DecLayer> dec;
     DevBuf dec_ln_g, dec_ln_b;
     DevBuf cross_kv_w, cross_kv_b;  // [L*2*d][d] rows: layer-major, K then V
+    // log-mel front end (lazy): constants + scratch sized for max_batch utterances
+    struct Frontend {
+        bool ready = false;
+        int chunk = 16;  // utterances per DFT GEMM
+        DevBuf window, dft, fb, band, pcm, frames, spec, logtmp, mel;
+    } fe;
     static const int NSLOT = 4;
     wm_state* cached = nullptr;           // slot 0: the state behind wm_transcribe / wm_transcribe_submit(slot 0)
     wm_state* slots[3] = {nullptr, nullptr, nullptr};  // slots 1..3: further pipeline stages (wm_transcribe_submit)
@@ -258,6 +264,10 @@ extern "C" void wm_model_free(wm_model* m) {
     if (m->cached) wm_state_free(m->cached);
     for (auto& sl : m->slots)
         if (sl) wm_state_free(sl);
+    {
+        DevBuf* fb[] = {&m->fe.window, &m->fe.dft, &m->fe.fb, &m->fe.band, &m->fe.pcm, &m->fe.frames, &m->fe.spec, &m->fe.logtmp, &m->fe.mel};
+        for (DevBuf* b : fb) b->release();
+    }
     DevBuf* top[] = {&m->conv1_w, &m->conv1_b, &m->conv2_w, &m->conv2_b, &m->enc_pos, &m->enc_ln_g, &m->enc_ln_b,
                      &m->tok_emb_f, &m->tok_emb_t, &m->dec_pos, &m->dec_ln_g, &m->dec_ln_b, &m->cross_kv_w, &m->cross_kv_b};
     for (DevBuf* b : top) b->release();
@@ -1145,6 +1155,118 @@ extern "C" int wm_transcribe_submit(wm_model* m, int slot, const float* mel, int
 extern "C" int wm_transcribe_wait(wm_model* m, int slot, int32_t* tokens_out, int32_t* n_tokens) {
     if (!m || !tokens_out || !n_tokens || slot < 0 || slot >= wm_model::NSLOT) return fail(WM_E_ARG, "bad argument");
     return wait_on(m, slot == 0 ? m->cached : m->slots[slot - 1], tokens_out, n_tokens);
+}
+
+// ---- log-mel front end: 16 kHz PCM -> [n_mels, n_frames]  (export_weights.py:100-116 delegates this to
+// HF WhisperProcessor = transformers feature_extraction_whisper._np_extract_fbank_features)
+static const int FE_NFFT = 400, FE_HOP = 160, FE_NFREQ = 201;
+
+static double hz_to_mel_slaney(double f) { return f >= 1000.0 ? 15.0 + std::log(f / 1000.0) * (27.0 / std::log(6.4)) : 3.0 * f / 200.0; }
+static double mel_to_hz_slaney(double m) { return m >= 15.0 ? 1000.0 * std::exp(std::log(6.4) / 27.0 * (m - 15.0)) : 200.0 * m / 3.0; }
+
+static int frontend_init(wm_model* m) {
+    if (m->fe.ready) return 0;
+    const wm_dims& c = m->cfg.dims;
+    const int n_mels = c.n_mels, n_frames = 2 * c.n_audio_ctx, N = FE_HOP * n_frames, maxB = m->cfg.max_batch;
+    const double PI = 3.14159265358979323846;
+    std::vector<float> window(FE_NFFT), dft((size_t)512 * 416, 0.f), fb((size_t)FE_NFREQ * n_mels, 0.f);
+    for (int n = 0; n < FE_NFFT; ++n) window[n] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * n / FE_NFFT));  // periodic Hann
+    for (int k = 0; k < FE_NFREQ; ++k)
+        for (int n = 0; n < FE_NFFT; ++n) {
+            const double ang = 2.0 * PI * (double)((k * n) % FE_NFFT) / FE_NFFT;
+            dft[(size_t)k * 416 + n] = (float)std::cos(ang);
+            dft[(size_t)(256 + k) * 416 + n] = (float)(-std::sin(ang));
+        }
+    // slaney-scale, slaney-normalised triangular filters (transformers.audio_utils.mel_filter_bank)
+    std::vector<double> ff(n_mels + 2);
+    const double m0 = hz_to_mel_slaney(0.0), m1 = hz_to_mel_slaney(8000.0);
+    for (int i = 0; i < n_mels + 2; ++i) ff[i] = mel_to_hz_slaney(m0 + (m1 - m0) * i / (n_mels + 1));
+    std::vector<int> band(2 * n_mels);
+    for (int mm = 0; mm < n_mels; ++mm) {
+        int lo = FE_NFREQ, hi = 0;
+        const double enorm = 2.0 / (ff[mm + 2] - ff[mm]);
+        for (int k = 0; k < FE_NFREQ; ++k) {
+            const double f = 8000.0 * k / (FE_NFREQ - 1);
+            const double down = (f - ff[mm]) / (ff[mm + 1] - ff[mm]), up = (ff[mm + 2] - f) / (ff[mm + 2] - ff[mm + 1]);
+            const double v = std::max(0.0, std::min(down, up)) * enorm;
+            fb[(size_t)k * n_mels + mm] = (float)v;
+            if (v > 0.0) {
+                lo = std::min(lo, k);
+                hi = std::max(hi, k + 1);
+            }
+        }
+        band[2 * mm] = lo < hi ? lo : 0;
+        band[2 * mm + 1] = lo < hi ? hi : 0;
+    }
+    WMCHK(upload(m->fe.window, window.data(), window.size(), WM_F32));
+    WMCHK(upload(m->fe.dft, dft.data(), dft.size(), WM_F32));
+    WMCHK(upload(m->fe.fb, fb.data(), fb.size(), WM_F32));
+    WMCHK(m->fe.band.alloc(band.size() * 4));
+    HIPCHK(hipMemcpy(m->fe.band.p, band.data(), band.size() * 4, hipMemcpyHostToDevice));
+    const size_t ch = std::min(maxB, m->fe.chunk);
+    const size_t rows = (ch * n_frames + 127) / 128 * 128 + 128;
+    WMCHK(m->fe.pcm.alloc((size_t)maxB * N * 4, true));
+    WMCHK(m->fe.frames.alloc(rows * 416 * 4, true));
+    WMCHK(m->fe.spec.alloc(rows * 512 * 4, true));
+    WMCHK(m->fe.logtmp.alloc((size_t)maxB * n_mels * n_frames * 4));
+    WMCHK(m->fe.mel.alloc((size_t)maxB * n_mels * n_frames * 4));
+    m->fe.ready = true;
+    return 0;
+}
+
+// pcm: host [B][stride] fp32 at 16 kHz; n_samples[b] valid samples (<= stride).  Result stays in m->fe.mel (device).
+static int frontend_run(wm_model* m, const float* pcm, const int32_t* n_samples, int B, int stride) {
+    if (!pcm || !n_samples || B <= 0 || stride <= 0) return fail(WM_E_ARG, "bad argument");
+    if (B > m->cfg.max_batch) return fail(WM_E_ARG, "batch %d exceeds max_batch %d", B, m->cfg.max_batch);
+    HIPCHK(hipSetDevice(m->device));
+    WMCHK(frontend_init(m));
+    const wm_dims& c = m->cfg.dims;
+    const int n_frames = 2 * c.n_audio_ctx, N = FE_HOP * n_frames;
+    hipStream_t st = m->stream;
+    HIPCHK(hipMemsetAsync(m->fe.pcm.p, 0, (size_t)B * N * 4, st));  // pad / trim to the 30 s window
+    for (int b = 0; b < B; ++b) {
+        if (n_samples[b] < 0 || n_samples[b] > stride) return fail(WM_E_ARG, "n_samples[%d]=%d out of range", b, n_samples[b]);
+        const size_t n = std::min(n_samples[b], N);
+        if (n) HIPCHK(hipMemcpyAsync(m->fe.pcm.as<float>() + (size_t)b * N, pcm + (size_t)b * stride, n * 4, hipMemcpyHostToDevice, st));
+    }
+    for (int c0 = 0; c0 < B; c0 += m->fe.chunk) {
+        const int bc = std::min(m->fe.chunk, B - c0);
+        launch_frames(m->fe.pcm.as<float>() + (size_t)c0 * N, m->fe.frames.as<float>(), m->fe.window.as<float>(), bc, N, n_frames, FE_HOP, st);
+        GemmParams p{};
+        p.A = m->fe.frames.p;
+        p.W = m->fe.dft.p;
+        p.C = m->fe.spec.p;
+        p.M = bc * n_frames;
+        p.N = 512;
+        p.K = 416;
+        p.lda = 416;
+        p.ldw = 416;
+        p.ldc = 512;
+        launch_gemm_nt<float, float>(p, 1, st);
+        launch_mel_log(m->fe.spec.as<float>(), m->fe.fb.as<float>(), m->fe.band.as<int>(), m->fe.logtmp.as<float>() + (size_t)c0 * c.n_mels * n_frames,
+                       bc, n_frames, c.n_mels, st);
+    }
+    launch_mel_norm(m->fe.logtmp.as<float>(), m->fe.mel.as<float>(), B, c.n_mels * n_frames, st);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wm_log_mel(wm_model* m, const float* pcm, const int32_t* n_samples, int B, int stride, float* mel_out) {
+    if (!m) return fail(WM_E_ARG, "null model");
+    WMCHK(frontend_run(m, pcm, n_samples, B, stride));
+    const wm_dims& c = m->cfg.dims;
+    if (mel_out) HIPCHK(hipMemcpyAsync(mel_out, m->fe.mel.p, (size_t)B * c.n_mels * 2 * c.n_audio_ctx * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+extern "C" int wm_transcribe_pcm(wm_model* m, const float* pcm, const int32_t* n_samples, int B, int stride, const wm_decode_opts* o,
+                                 int32_t* tokens_out, int32_t* n_tokens) {
+    if (!m || !tokens_out || !n_tokens) return fail(WM_E_ARG, "bad argument");
+    WMCHK(check_opts(m, o, B));
+    WMCHK(frontend_run(m, pcm, n_samples, B, stride));  // same stream as the encoder: ordered, no host sync
+    WMCHK(submit_on(m, &m->cached, m->fe.mel.as<float>(), 1, B, o, true));
+    return wait_on(m, m->cached, tokens_out, n_tokens);
 }
 
 // ---- measurement helpers ------------------------------------------------------------------------------------------------

@@ -117,6 +117,11 @@ void launch_advance(StepCtl* ctl, int* pos, int B, hipStream_t st);
 void launch_set_step(StepCtl* ctl, int len, int set_len, int* pos, int pos_value, int* tok, int tok_value, int B,
                      hipStream_t st);
 
+// ---- log-mel front end (kernels_frontend.hip) ------------------------------------------------------------------------
+void launch_frames(const float* pcm, float* F, const float* window, int B, int N, int n_frames, int hop, hipStream_t st);
+void launch_mel_log(const float* spec, const float* fb, const int* band, float* logmel, int B, int n_frames, int n_mels, hipStream_t st);
+void launch_mel_norm(const float* logmel, float* out, int B, int n, hipStream_t st);
+
 // ---- small ops for the op-level C-ABI ----------------------------------------------------------------------------
 void launch_gelu(float* t, size_t n, int mode, hipStream_t st);
 void launch_softmax_rows(float* t, int rows, int cols, hipStream_t st);
