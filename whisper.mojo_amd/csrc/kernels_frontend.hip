@@ -25,6 +25,15 @@ __global__ __launch_bounds__(128) void frames_kernel(const float* __restrict__ p
         row[n] = v;
     }
 }
+// x[b][i] = 0 for i >= len[b] (zero padding of short clips after the one-shot strided upload)
+__global__ void zero_tails_kernel(float* __restrict__ pcm, const int* __restrict__ len, int N) {
+    float* x = pcm + (size_t)blockIdx.y * N;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N && i >= len[blockIdx.y]) x[i] = 0.f;
+}
+void launch_zero_tails(float* pcm, const int* len, int B, int N, hipStream_t st) {
+    hipLaunchKernelGGL(zero_tails_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, pcm, len, N);
+}
 void launch_frames(const float* pcm, float* F, const float* window, int B, int N, int n_frames, int hop, hipStream_t st) {
     hipLaunchKernelGGL(frames_kernel, dim3(n_frames, B), dim3(128), 0, st, pcm, F, window, N, n_frames, hop);
 }

@@ -126,7 +126,7 @@ struct wm_model {
     struct Frontend {
         bool ready = false;
         int chunk = 16;  // utterances per DFT GEMM
-        DevBuf window, dft, fb, band, pcm, frames, spec, logtmp, mel;
+        DevBuf window, dft, fb, band, pcm, lens, frames, spec, logtmp, mel;
     } fe;
     static const int NSLOT = 4;
     wm_state* cached = nullptr;           // slot 0: the state behind wm_transcribe / wm_transcribe_submit(slot 0)
@@ -265,7 +265,7 @@ extern "C" void wm_model_free(wm_model* m) {
     for (auto& sl : m->slots)
         if (sl) wm_state_free(sl);
     {
-        DevBuf* fb[] = {&m->fe.window, &m->fe.dft, &m->fe.fb, &m->fe.band, &m->fe.pcm, &m->fe.frames, &m->fe.spec, &m->fe.logtmp, &m->fe.mel};
+        DevBuf* fb[] = {&m->fe.window, &m->fe.dft, &m->fe.fb, &m->fe.band, &m->fe.pcm, &m->fe.lens, &m->fe.frames, &m->fe.spec, &m->fe.logtmp, &m->fe.mel};
         for (DevBuf* b : fb) b->release();
     }
     DevBuf* top[] = {&m->conv1_w, &m->conv1_b, &m->conv2_w, &m->conv2_b, &m->enc_pos, &m->enc_ln_g, &m->enc_ln_b,
@@ -1206,6 +1206,7 @@ static int frontend_init(wm_model* m) {
     const size_t ch = std::min(maxB, m->fe.chunk);
     const size_t rows = (ch * n_frames + 127) / 128 * 128 + 128;
     WMCHK(m->fe.pcm.alloc((size_t)maxB * N * 4, true));
+    WMCHK(m->fe.lens.alloc((size_t)maxB * 4, true));
     WMCHK(m->fe.frames.alloc(rows * 416 * 4, true));
     WMCHK(m->fe.spec.alloc(rows * 512 * 4, true));
     WMCHK(m->fe.logtmp.alloc((size_t)maxB * n_mels * n_frames * 4));
@@ -1223,12 +1224,14 @@ static int frontend_run(wm_model* m, const float* pcm, const int32_t* n_samples,
     const wm_dims& c = m->cfg.dims;
     const int n_frames = 2 * c.n_audio_ctx, N = FE_HOP * n_frames;
     hipStream_t st = m->stream;
-    HIPCHK(hipMemsetAsync(m->fe.pcm.p, 0, (size_t)B * N * 4, st));  // pad / trim to the 30 s window
-    for (int b = 0; b < B; ++b) {
+    // pad / trim to the 30 s window: ONE strided upload of the common prefix, then a kernel zeroes each utterance's tail
+    for (int b = 0; b < B; ++b)
         if (n_samples[b] < 0 || n_samples[b] > stride) return fail(WM_E_ARG, "n_samples[%d]=%d out of range", b, n_samples[b]);
-        const size_t n = std::min(n_samples[b], N);
-        if (n) HIPCHK(hipMemcpyAsync(m->fe.pcm.as<float>() + (size_t)b * N, pcm + (size_t)b * stride, n * 4, hipMemcpyHostToDevice, st));
-    }
+    const size_t w = std::min(stride, N);
+    if (w < (size_t)N) HIPCHK(hipMemsetAsync(m->fe.pcm.p, 0, (size_t)B * N * 4, st));
+    HIPCHK(hipMemcpy2DAsync(m->fe.pcm.p, (size_t)N * 4, pcm, (size_t)stride * 4, w * 4, B, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(m->fe.lens.p, n_samples, (size_t)B * 4, hipMemcpyHostToDevice, st));
+    launch_zero_tails(m->fe.pcm.as<float>(), m->fe.lens.as<int>(), B, N, st);
     for (int c0 = 0; c0 < B; c0 += m->fe.chunk) {
         const int bc = std::min(m->fe.chunk, B - c0);
         launch_frames(m->fe.pcm.as<float>() + (size_t)c0 * N, m->fe.frames.as<float>(), m->fe.window.as<float>(), bc, N, n_frames, FE_HOP, st);

@@ -118,6 +118,7 @@ void launch_set_step(StepCtl* ctl, int len, int set_len, int* pos, int pos_value
                      hipStream_t st);
 
 // ---- log-mel front end (kernels_frontend.hip) ------------------------------------------------------------------------
+void launch_zero_tails(float* pcm, const int* len, int B, int N, hipStream_t st);
 void launch_frames(const float* pcm, float* F, const float* window, int B, int N, int n_frames, int hop, hipStream_t st);
 void launch_mel_log(const float* spec, const float* fb, const int* band, float* logmel, int B, int n_frames, int n_mels, hipStream_t st);
 void launch_mel_norm(const float* logmel, float* out, int B, int n, hipStream_t st);
