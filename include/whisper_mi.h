@@ -46,6 +46,13 @@ typedef struct {
     int max_loop;   /* reference: 195 -> at most n_prompt + 1 + 195 ids per utterance */
     int pos_mode;   /* WM_POS_* */
     int ignore_eot; /* != 0: "fixed" mode — never stop early (bench) */
+    /* SURVEY §8f rank 4 — logit masks the reference lacks (whisper.mojo:198,219 take the raw argmax), with the semantics
+     * of HF generate's SuppressTokensLogitsProcessor / SuppressTokensAtBeginLogitsProcessor; applied inside the fused
+     * argmax, never to the logits wm_decode_step returns.  NULL / 0 = none (the reference's behaviour). */
+    const int32_t* suppress_tokens;       /* ids that can never be emitted */
+    int n_suppress;
+    const int32_t* begin_suppress_tokens; /* ids that cannot be the FIRST generated token */
+    int n_begin_suppress;
 } wm_decode_opts;
 
 typedef struct wm_model wm_model;

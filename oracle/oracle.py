@@ -66,6 +66,8 @@ def lib():
         L.wo_decoder_forward.argtypes = [C.c_void_p, ip, C.c_int, fp, C.c_void_p, C.c_int, fp]
         L.wo_transcribe.argtypes = [C.c_void_p, fp, fp, ip, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, fp]
         L.wo_transcribe.restype = C.c_int
+        L.wo_transcribe_ex.argtypes = [C.c_void_p, fp, fp, ip, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, C.c_int, ip, C.c_int, ip, fp]
+        L.wo_transcribe_ex.restype = C.c_int
         L.wo_teacher_forced.argtypes = [C.c_void_p, fp, ip, C.c_int, C.c_int, C.c_int, fp]
         L.wo_synth_count.argtypes = [C.POINTER(WmDims)]
         L.wo_synth_count.restype = C.c_size_t
@@ -208,14 +210,16 @@ class OracleModel:
         return out
 
     def transcribe(self, mel=None, enc_out=None, prompt=(50258, 50259, 50359, 50363), eot=50257, max_loop=195,
-                   pos_mode=0, ignore_eot=False, want_logits=False):
+                   pos_mode=0, ignore_eot=False, want_logits=False, suppress_tokens=(), begin_suppress_tokens=()):
         p = np.asarray(prompt, np.int32)
         toks = np.zeros(len(p) + 1 + max_loop, np.int32)
         logits = np.zeros((1 + max_loop, self.cfg.vocab_size), np.float32) if want_logits else None
         m = None if mel is None else _f32(mel)
         e = None if enc_out is None else _f32(enc_out)
-        n = lib().wo_transcribe(self._h, _fp(m), _fp(e), _ip(p), len(p), eot, max_loop, pos_mode, int(ignore_eot),
-                                _ip(toks), _fp(logits))
+        sup = np.asarray(list(suppress_tokens) or [0], np.int32)
+        bsup = np.asarray(list(begin_suppress_tokens) or [0], np.int32)
+        n = lib().wo_transcribe_ex(self._h, _fp(m), _fp(e), _ip(p), len(p), eot, max_loop, pos_mode, int(ignore_eot),
+                                   _ip(sup), len(suppress_tokens), _ip(bsup), len(begin_suppress_tokens), _ip(toks), _fp(logits))
         toks = toks[:n].copy()
         if want_logits:
             return toks, logits[:n - len(p)].copy()

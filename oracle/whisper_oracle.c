@@ -626,8 +626,16 @@ void wo_decoder_forward(const wo_model* m, const int32_t* tokens, int L_tgt, con
  * If enc_in != NULL it is used instead of running the encoder (stage-level tests).
  * If logits_out != NULL it receives (1+iterations) rows of vocab logits.
  * Returns the number of ids written to tokens_out (<= n_prompt + 1 + max_loop). */
-int wo_transcribe(const wo_model* m, const float* mel, const float* enc_in, const int32_t* prompt, int n_prompt,
-                  int eot, int max_loop, int pos_mode, int ignore_eot, int32_t* tokens_out, float* logits_out) {
+static void suppress(float* logits, const int32_t* ids, int n, int V) {
+    for (int i = 0; i < n; ++i)
+        if (ids[i] >= 0 && ids[i] < V) logits[ids[i]] = -INFINITY;
+}
+/* SURVEY §8f rank 4 (absent from the reference, whisper.mojo:198,219 use the raw argmax): HF generate's
+ * SuppressTokensLogitsProcessor (ids set to -inf at EVERY step) and SuppressTokensAtBeginLogitsProcessor (ids set to
+ * -inf for the FIRST generated token only), transformers/generation/logits_process.py.  logits_out rows stay raw. */
+int wo_transcribe_ex(const wo_model* m, const float* mel, const float* enc_in, const int32_t* prompt, int n_prompt,
+                     int eot, int max_loop, int pos_mode, int ignore_eot, const int32_t* sup, int n_sup,
+                     const int32_t* bsup, int n_bsup, int32_t* tokens_out, float* logits_out) {
     const int d = m->cfg.d_model, T = m->cfg.n_audio_ctx, V = m->cfg.vocab;
     float* enc_out = (float*)malloc(sizeof(float) * (size_t)T * d);
     if (enc_in)
@@ -640,6 +648,8 @@ int wo_transcribe(const wo_model* m, const float* mel, const float* enc_in, cons
     for (int i = 0; i < n_prompt; ++i) tokens_out[n++] = prompt[i];
     wo_decoder_forward(m, prompt, n_prompt, enc_out, cache, 0, logits);
     if (logits_out) memcpy(logits_out + (size_t)(row++) * V, logits, sizeof(float) * V);
+    suppress(logits, sup, n_sup, V);
+    suppress(logits, bsup, n_bsup, V);
     int next = wo_argmax(logits, V);
     tokens_out[n++] = next;
     for (int it = 0; it < max_loop; ++it) {
@@ -648,6 +658,7 @@ int wo_transcribe(const wo_model* m, const float* mel, const float* enc_in, cons
         int start_pos = pos_mode == 0 ? cache->layers[0].current_len - 1 : cache->layers[0].current_len;
         wo_decoder_forward(m, &last, 1, enc_out, cache, start_pos, logits);
         if (logits_out) memcpy(logits_out + (size_t)(row++) * V, logits, sizeof(float) * V);
+        suppress(logits, sup, n_sup, V);
         next = wo_argmax(logits, V);
         tokens_out[n++] = next;
     }
@@ -655,6 +666,11 @@ int wo_transcribe(const wo_model* m, const float* mel, const float* enc_in, cons
     wo_cache_free(cache);
     free(enc_out);
     return n;
+}
+int wo_transcribe(const wo_model* m, const float* mel, const float* enc_in, const int32_t* prompt, int n_prompt,
+                  int eot, int max_loop, int pos_mode, int ignore_eot, int32_t* tokens_out, float* logits_out) {
+    return wo_transcribe_ex(m, mel, enc_in, prompt, n_prompt, eot, max_loop, pos_mode, ignore_eot, NULL, 0, NULL, 0, tokens_out,
+                            logits_out);
 }
 
 /* Teacher-forced variant for tolerance tests: feeds forced[0..n_forced) (n_prompt prompt ids first, then the

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n = n0 + nb * 16 + g * 4 + r;
-                    const float v = acc[nb][rb][r];
+                    const float v = acc[nb][rb][r] + (p.amax_mask ? p.amax_mask[min(n, p.N - 1)] : 0.f);  // 0 or -inf
                     if (n < p.N && v > bv) {  // n increases through the loop: strict '>' keeps the lowest index
                         bv = v;
                         bi = n;
@@ -742,15 +742,6 @@ void launch_init_tokens(const InitTokensParams& p, hipStream_t st) {
     hipLaunchKernelGGL(init_tokens_kernel, dim3((p.B + 255) / 256), dim3(256), 0, st, p);
 }
 
-// current_len += 1 (layers.mojo:143) and every utterance's position += 1
-__global__ void advance_kernel(StepCtl* ctl, int* pos, int B) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) pos[i] += 1;
-    if (i == 0) ctl->len += 1;
-}
-void launch_advance(StepCtl* ctl, int* pos, int B, hipStream_t st) {
-    hipLaunchKernelGGL(advance_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ctl, pos, B);
-}
 __global__ void set_step_kernel(StepCtl* ctl, int len, int set_len, int* pos, int pos_value, int* tok, int tok_value, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B) {
@@ -807,22 +798,6 @@ template <typename T> void launch_convert(const float* in, void* out, size_t n, 
 template void launch_convert<float>(const float*, void*, size_t, hipStream_t);
 template void launch_convert<bf16>(const float*, void*, size_t, hipStream_t);
 template void launch_convert<f16>(const float*, void*, size_t, hipStream_t);
-// in [rows][cols] fp32 -> out [rows][cols_pad] T, zero padded columns
-template <typename T> __global__ void pad_rows_kernel(const float* in, T* out, int rows, int cols, int cols_pad) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (size_t)rows * cols_pad) {
-        int r = (int)(i / cols_pad), c = (int)(i % cols_pad);
-        out[i] = from_f32<T>(c < cols ? in[(size_t)r * cols + c] : 0.f);
-    }
-}
-template <typename T> void launch_pad_rows(const float* in, void* out, int rows, int cols, int cols_pad, hipStream_t st) {
-    size_t n = (size_t)rows * cols_pad;
-    hipLaunchKernelGGL(pad_rows_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, (T*)out, rows, cols,
-                       cols_pad);
-}
-template void launch_pad_rows<float>(const float*, void*, int, int, int, hipStream_t);
-template void launch_pad_rows<bf16>(const float*, void*, int, int, int, hipStream_t);
-template void launch_pad_rows<f16>(const float*, void*, int, int, int, hipStream_t);
 __global__ void transpose_f32_kernel(const float* in, float* out, int rows, int cols) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (size_t)rows * cols) {

@@ -165,6 +165,9 @@ struct wm_state {
     DevBuf cross_kv;         // [L][2][B][n_ctx][d] kv dtype
     DevBuf self_kv;          // [L][2][B][n_text_ctx][d]
     // decode arena
+    DevBuf mask_steady, mask_begin;  // [Vpad] additive logit masks (0 / -inf) for the fused argmax
+    std::vector<int32_t> sup_cached, bsup_cached;
+    bool masks_valid = false;
     DevBuf dx, dq, dattn, dhid, part_o, part_ml, logits, amax_val, amax_idx, tok, pos, ctl, out_tokens, n_tokens, finished;
     int npart = 0;  // fused-argmax partials per utterance = ceil(vocab / 128)
 };
@@ -441,7 +444,7 @@ extern "C" void wm_state_free(wm_state* s) {
     if (s->enc_done) (void)hipEventDestroy(s->enc_done);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     DevBuf* bs[] = {&s->mel_dev, &s->mel_t, &s->h1, &s->x, &s->xn, &s->qkv, &s->ao, &s->hid, &s->enc_t, &s->enc_f,
-                    &s->cross_kv, &s->self_kv, &s->dx, &s->dq, &s->dattn, &s->dhid, &s->part_o, &s->part_ml, &s->logits, &s->amax_val, &s->amax_idx,
+                    &s->cross_kv, &s->self_kv, &s->dx, &s->dq, &s->dattn, &s->dhid, &s->part_o, &s->part_ml, &s->logits, &s->amax_val, &s->amax_idx, &s->mask_steady, &s->mask_begin,
                     &s->tok, &s->pos, &s->ctl, &s->out_tokens, &s->n_tokens, &s->finished};
     for (DevBuf* b : bs) b->release();
     delete s;
@@ -493,6 +496,8 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
     s->npart = (c.vocab + 127) / 128;
     A(s->amax_val, (size_t)B * s->npart * 4);
     A(s->amax_idx, (size_t)B * s->npart * 4);
+    A(s->mask_steady, (size_t)m->Vpad * 4, true);
+    A(s->mask_begin, (size_t)m->Vpad * 4, true);
     A(s->tok, (size_t)B * 4, true);
     A(s->pos, (size_t)B * 4, true);
     A(s->ctl, sizeof(StepCtl) * 8, true);  // [0] whole-batch control (wm_decode_step), [1..] one per decode lane
@@ -766,7 +771,6 @@ static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v)
     a.V = off_bytes(s->cross_kv, ((size_t)(2 * l + 1) * cross_l + boff) * ks);
     a.batch_stride = (long)((size_t)c.n_audio_ctx * d);
     a.n_keys = c.n_audio_ctx;
-    if (const char* e = getenv("WM_DEBUG_NKEYS")) a.n_keys = atoi(e);  // experiments only: wrong results
     a.ctl = v.ctl;
     a.nsplit = s->nsplit;
     a.scale = 1.0f / sqrtf(64.0f);
@@ -780,7 +784,8 @@ static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v)
 
 // want_logits: run the final LN + vocabulary projection.  full_logits: also materialise [B, vocab] fp32 (stage tests,
 // wm_decode_step); the greedy loop only needs the fused-argmax partials.
-static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_logits, bool full_logits = false) {
+static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_logits, bool full_logits = false,
+                        const float* mask = nullptr) {
     const wm_dims& c = m->cfg.dims;
     const int T = m->cfg.compute_dtype, KV = m->cfg.kv_dtype;
     const int B = v.nb;
@@ -907,6 +912,7 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
         p.amax_val = s->amax_val.as<float>() + (size_t)v.b0 * s->npart;
         p.amax_idx = s->amax_idx.as<int>() + (size_t)v.b0 * s->npart;
         p.amax_stride = s->npart;
+        p.amax_mask = mask;
         DISPATCH_DT(T, TT, launch_dec_logits<TT>(p, st));
     }
 }
@@ -987,6 +993,23 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
     static const bool no_graph = getenv("WM_NO_GRAPH") != nullptr;
     const bool recapture = !s->graphs_valid || s->graph_eot != o->eot || s->graph_ignore != o->ignore_eot;
     const int first_pos = o->pos_mode == WM_POS_REF ? o->n_prompt - 1 : o->n_prompt;
+    // logit masks (§8f rank 4): rebuilt only when the id lists change; always passed (all-zero = the reference's raw argmax)
+    {
+        std::vector<int32_t> sup(o->suppress_tokens, o->suppress_tokens + (o->suppress_tokens ? o->n_suppress : 0));
+        std::vector<int32_t> bsup(o->begin_suppress_tokens, o->begin_suppress_tokens + (o->begin_suppress_tokens ? o->n_begin_suppress : 0));
+        if (!s->masks_valid || sup != s->sup_cached || bsup != s->bsup_cached) {
+            std::vector<float> ms(m->Vpad, 0.f), mb(m->Vpad, 0.f);
+            for (int32_t id : sup)
+                if (id >= 0 && id < m->cfg.dims.vocab) ms[id] = mb[id] = -INFINITY;
+            for (int32_t id : bsup)
+                if (id >= 0 && id < m->cfg.dims.vocab) mb[id] = -INFINITY;
+            HIPCHK(hipMemcpy(s->mask_steady.p, ms.data(), ms.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(s->mask_begin.p, mb.data(), mb.size() * 4, hipMemcpyHostToDevice));
+            s->sup_cached = sup;
+            s->bsup_cached = bsup;
+            s->masks_valid = true;
+        }
+    }
     InitTokensParams ip{};
     ip.n_prompt = o->n_prompt;
     for (int i = 0; i < o->n_prompt; ++i) ip.prompt[i] = o->prompt[i];
@@ -1004,7 +1027,7 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
         // prefill (whisper.mojo:195, start_pos=0): the q_len = n_prompt causal block equals n_prompt single-token steps
         for (int i = 0; i < o->n_prompt; ++i) {
             launch_set_step(v.ctl, i, 1, s->pos.as<int>() + v.b0, i, s->tok.as<int>() + v.b0, o->prompt[i], v.nb, v.st);
-            decode_core(m, s, v, i == o->n_prompt - 1);
+            decode_core(m, s, v, i == o->n_prompt - 1, false, s->mask_begin.as<float>());
         }
         launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot), v.st);  // :198-203
         // incremental steps: start_pos = current_len - 1 (reference, :217) or current_len (HF)
@@ -1018,7 +1041,7 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
             }
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(v.st, hipStreamCaptureModeThreadLocal));
-            decode_core(m, s, v, true);
+            decode_core(m, s, v, true, false, s->mask_steady.as<float>());
             launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, true), v.st);
             HIPCHK(hipStreamEndCapture(v.st, &g));
             hipError_t ge = hipSuccess;
@@ -1060,7 +1083,7 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
                 }
             } else {
                 const DecView v{ln.b0, ln.nb, ln.st, ln.ctl};
-                decode_core(m, s, v, true);
+                decode_core(m, s, v, true, false, s->mask_steady.as<float>());
                 launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, true), v.st);
             }
         }
@@ -1082,6 +1105,8 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
 static int check_opts(wm_model* m, const wm_decode_opts* o, int B) {
     if (!o || B <= 0) return fail(WM_E_ARG, "bad argument");
     if (!o->prompt || o->n_prompt <= 0 || o->n_prompt > 16 || o->max_loop < 0) return fail(WM_E_ARG, "bad decode options (1 <= n_prompt <= 16)");
+    if (o->n_suppress < 0 || o->n_begin_suppress < 0 || (o->n_suppress > 0 && !o->suppress_tokens) || (o->n_begin_suppress > 0 && !o->begin_suppress_tokens))
+        return fail(WM_E_ARG, "bad suppress-token lists");
     const wm_dims& c = m->cfg.dims;
     const int total = o->n_prompt + 1 + o->max_loop;
     if (total > c.n_text_ctx + 1 || total > OUT_STRIDE_MAX)

@@ -44,7 +44,6 @@ template <> __device__ __forceinline__ Frag<f16> load_frag<f16>(const f16* p) {
 }
 
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
-template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 
 // fragment from 8 fp32 values (activations normalised on the fly)
 template <typename T> __device__ __forceinline__ Frag<T> make_frag(const float (&x)[8]) {

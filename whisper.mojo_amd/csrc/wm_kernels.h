@@ -60,6 +60,7 @@ struct DecLinearParams {
     float* amax_val;  // [B][amax_stride] or null
     int* amax_idx;
     int amax_stride;
+    const float* amax_mask;  // [N] additive mask (0 / -inf) applied to the argmax candidates only, or null
 };
 template <typename TW> void launch_dec_linear(const DecLinearParams& p, hipStream_t st);
 template <typename TW> void launch_dec_logits(const DecLinearParams& p, hipStream_t st);
@@ -113,7 +114,6 @@ struct InitTokensParams {
     int prompt[16];
 };
 void launch_init_tokens(const InitTokensParams& p, hipStream_t st);
-void launch_advance(StepCtl* ctl, int* pos, int B, hipStream_t st);
 void launch_set_step(StepCtl* ctl, int len, int set_len, int* pos, int pos_value, int* tok, int tok_value, int B,
                      hipStream_t st);
 
@@ -128,7 +128,6 @@ void launch_gelu(float* t, size_t n, int mode, hipStream_t st);
 void launch_softmax_rows(float* t, int rows, int cols, hipStream_t st);
 void launch_argmax_plain(const float* t, int n, int* idx, hipStream_t st);
 template <typename T> void launch_convert(const float* in, void* out, size_t n, hipStream_t st);
-template <typename T> void launch_pad_rows(const float* in, void* out, int rows, int cols, int cols_pad, hipStream_t st);
 void launch_transpose_f32(const float* in, float* out, int rows, int cols, hipStream_t st);
 
 }  // namespace wm

@@ -40,7 +40,7 @@ def transcribe_audio(model, audios: Sequence[np.ndarray], prompt: Sequence[int] 
     buf, n, stride = _pack(audios)
     p = np.asarray(prompt, np.int32)
     fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
-    opts = _lib.WmDecodeOpts(p.ctypes.data_as(ip), len(p), eot, max_loop, model.pos_mode, int(ignore_eot))
+    opts = _lib.WmDecodeOpts(p.ctypes.data_as(ip), len(p), eot, max_loop, model.pos_mode, int(ignore_eot), None, 0, None, 0)
     total = len(p) + 1 + max_loop
     toks = np.zeros((len(audios), total), np.int32)
     cnt = np.zeros(len(audios), np.int32)

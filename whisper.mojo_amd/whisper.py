@@ -168,14 +168,23 @@ class Whisper:
         except Exception:
             pass
 
+    def _opts(self, prompt, eot, max_loop, ignore_eot, suppress_tokens=(), begin_suppress_tokens=()):
+        p = np.asarray(prompt, np.int32)
+        sup = np.asarray(list(suppress_tokens), np.int32)
+        bsup = np.asarray(list(begin_suppress_tokens), np.int32)
+        opts = _lib.WmDecodeOpts(_ip(p), len(p), eot, max_loop, self.pos_mode, int(ignore_eot),
+                                 _ip(sup) if len(sup) else None, len(sup), _ip(bsup) if len(bsup) else None, len(bsup))
+        return opts, (p, sup, bsup)
+
     def transcribe_batch(self, mel, prompt: Sequence[int] = PROMPT, eot: int = EOT, max_loop: int = MAX_LOOP,
-                         ignore_eot: bool = False) -> List[List[int]]:
+                         ignore_eot: bool = False, suppress_tokens: Sequence[int] = (),
+                         begin_suppress_tokens: Sequence[int] = ()) -> List[List[int]]:
         """Batched Whisper.transcribe: one List[int] per utterance = prompt + generated ids (+ eot when hit)."""
         if self._h is None:
             raise _lib.WhisperMiError("model not loaded")
         ptr, on_dev, B, keep = _mel_arg(mel, self.config)
-        p = np.asarray(prompt, np.int32)
-        opts = _lib.WmDecodeOpts(_ip(p), len(p), eot, max_loop, self.pos_mode, int(ignore_eot))
+        opts, keep2 = self._opts(prompt, eot, max_loop, ignore_eot, suppress_tokens, begin_suppress_tokens)
+        p = keep2[0]
         total = len(p) + 1 + max_loop
         toks = np.zeros((B, total), np.int32)
         n = np.zeros(B, np.int32)
@@ -191,8 +200,8 @@ class Whisper:
         if self._h is None:
             raise _lib.WhisperMiError("model not loaded")
         ptr, on_dev, B, keep = _mel_arg(mel, self.config)
-        p = np.asarray(prompt, np.int32)
-        opts = _lib.WmDecodeOpts(_ip(p), len(p), eot, max_loop, self.pos_mode, int(ignore_eot))
+        opts, keep2 = self._opts(prompt, eot, max_loop, ignore_eot)
+        p = keep2[0]
         _lib.check(_lib.lib().wm_transcribe_submit(self._h, slot, ptr, on_dev, B, C.byref(opts)))
         self._pending = getattr(self, "_pending", {})
         self._pending[slot] = (B, len(p) + 1 + max_loop, keep)
