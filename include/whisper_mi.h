@@ -69,6 +69,15 @@ int wm_model_load_memory(const float* weights, size_t n_floats, const wm_config*
 void wm_model_free(wm_model* m);
 size_t wm_weight_count(const wm_dims* dims);
 
+/* ---- weight file format v2 ------------------------------------------------------------------------
+ * v1 = the reference's headerless fp32 dump.  v2 = 64-byte header (magic "WMIWGT2", version, matrix dtype, dims, flags,
+ * payload size) + the same tensors in the same order, conv / linear matrices in `dtype` (WM_F32 / WM_BF16 / WM_F16), all
+ * vectors and positional tables in fp32; the token embedding stays fp32 when emb_f32 != 0 (then a v2 file in the model's
+ * compute dtype loads to exactly the weights the v1 file gives).  wm_model_load accepts either format and validates
+ * size / dims.  wm_weights_read expands either format to the fp32 image (wm_weight_count(dims) floats).  Host-only. */
+int wm_weights_convert_v2(const char* v1_path, const char* v2_path, const wm_dims* dims, int dtype, int emb_f32);
+int wm_weights_read(const char* path, const wm_dims* dims, float* out);
+
 /* ---- KVCache(n_layers, d_model, 448)   layers.mojo:55-63 — one per batch of B utterances ------------------- */
 int wm_state_new(wm_model* m, int batch, wm_state** out);
 int wm_state_reset(wm_state* s); /* current_len = 0, has_cross = false */

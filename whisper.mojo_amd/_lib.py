@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libwhispermi.so")
 
 # every symbol include/whisper_mi.h declares (tests/test_cabi_symbols.py checks the .so exports all of them)
 SYMBOLS = [
-    "wm_last_error", "wm_model_load", "wm_model_load_memory", "wm_model_free", "wm_weight_count", "wm_state_new",
+    "wm_last_error", "wm_model_load", "wm_model_load_memory", "wm_model_free", "wm_weight_count", "wm_weights_convert_v2", "wm_weights_read", "wm_state_new",
     "wm_state_reset", "wm_state_free", "wm_state_len", "wm_encode", "wm_state_set_encoder_output", "wm_decode_step",
     "wm_transcribe", "wm_transcribe_submit", "wm_transcribe_wait", "wm_log_mel", "wm_transcribe_pcm", "wm_op_matmul_nt", "wm_op_layer_norm", "wm_op_gelu", "wm_op_softmax_rows", "wm_op_conv1d_k3",
     "wm_op_argmax", "wm_bench_kernel", "wm_bench_bytes", "wm_synth_weights", "wm_synth_mel_host",
@@ -56,6 +56,8 @@ def lib():
     L.wm_model_free.restype = None
     L.wm_weight_count.argtypes = [C.POINTER(WmDims)]
     L.wm_weight_count.restype = C.c_size_t
+    L.wm_weights_convert_v2.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(WmDims), C.c_int, C.c_int]
+    L.wm_weights_read.argtypes = [C.c_char_p, C.POINTER(WmDims), fp]
     L.wm_state_new.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.wm_state_reset.argtypes = [vp]
     L.wm_state_free.argtypes = [vp]

@@ -411,23 +411,149 @@ extern "C" int wm_model_load_memory(const float* weights, size_t n_floats, const
     return 0;
 }
 
-extern "C" int wm_model_load(const char* path, const wm_config* cfg, int device, wm_model** out) {
-    if (!path || !cfg || !out) return fail(WM_E_ARG, "null argument");
-    WMCHK(check_cfg(cfg));
+// ---- weight file formats ------------------------------------------------------------------------------------------
+// v1: the reference's headerless fp32 dump (export_weights.py:19-90; loader.mojo reads it with no size check).
+// v2: 64-byte header {magic "WMIWGT2", version, matrix dtype, dims, flags, payload bytes} + the same
+// tensors in the same order; conv / linear matrices (and, unless flag bit 0 is set, the token embedding) stored in the
+// matrix dtype, every vector and positional table in fp32.  Loading v2 expands to the fp32 image the builder takes, so a
+// v2 file in the model's compute dtype gives bit-identical weights to the v1 file (16-bit rounding is idempotent).
+struct WmV2Header {
+    char magic[8];
+    uint32_t version, matrix_dtype;
+    int32_t dims[8];
+    uint32_t flags, reserved;
+    uint64_t payload_bytes;
+};
+static_assert(sizeof(WmV2Header) == 64, "v2 header is 64 bytes");
+static const char WM_V2_MAGIC[8] = {'W', 'M', 'I', 'W', 'G', 'T', '2', '\0'};
+enum { WM_V2_EMB_F32 = 1 };
+
+struct TensorSpan {
+    int kind;
+    size_t count;
+};
+static void collect_tensor(void* user, int, int kind, size_t count) { ((std::vector<TensorSpan>*)user)->push_back({kind, count}); }
+static bool v2_is_matrix(int kind, uint32_t flags) { return kind == WM_K_WEIGHT || kind == WM_K_QK || (kind == WM_K_EMB && !(flags & WM_V2_EMB_F32)); }
+static size_t v2_payload_bytes(const wm_dims* d, int dtype, uint32_t flags) {
+    std::vector<TensorSpan> t;
+    wm_synth_walk(d, collect_tensor, &t);
+    size_t n = 0;
+    for (auto& s : t) n += s.count * (v2_is_matrix(s.kind, flags) ? dt_size(dtype) : 4);
+    return n;
+}
+static inline float bf16_to_f32_host(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline float f16_to_f32_host(uint16_t h) {
+    _Float16 x;
+    memcpy(&x, &h, 2);
+    return (float)x;
+}
+
+extern "C" int wm_weights_convert_v2(const char* v1_path, const char* v2_path, const wm_dims* dims, int dtype, int emb_f32) {
+    if (!v1_path || !v2_path || !dims || dtype < 0 || dtype > 2) return fail(WM_E_ARG, "bad argument");
+    const size_t n = wm_synth_count(dims);
+    FILE* f = fopen(v1_path, "rb");
+    if (!f) return fail(WM_E_IO, "cannot open %s", v1_path);
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz < 0 || (size_t)sz != n * 4) {
+        fclose(f);
+        return fail(WM_E_SIZE, "%s is %ld bytes, these dims need %zu", v1_path, sz, n * 4);
+    }
+    std::vector<float> w(n);
+    const size_t got = fread(w.data(), 4, n, f);
+    fclose(f);
+    if (got != n) return fail(WM_E_IO, "short read on %s", v1_path);
+    WmV2Header h{};
+    memcpy(h.magic, WM_V2_MAGIC, 8);
+    h.version = 2;
+    h.matrix_dtype = (uint32_t)dtype;
+    memcpy(h.dims, dims, sizeof h.dims);
+    h.flags = emb_f32 ? WM_V2_EMB_F32 : 0;
+    h.payload_bytes = v2_payload_bytes(dims, dtype, h.flags);
+    FILE* o = fopen(v2_path, "wb");
+    if (!o) return fail(WM_E_IO, "cannot create %s", v2_path);
+    bool ok = fwrite(&h, sizeof h, 1, o) == 1;
+    std::vector<TensorSpan> t;
+    wm_synth_walk(dims, collect_tensor, &t);
+    size_t off = 0;
+    std::vector<uint16_t> tmp;
+    for (auto& s : t) {
+        if (v2_is_matrix(s.kind, h.flags) && dtype != WM_F32) {
+            tmp.resize(s.count);
+            for (size_t i = 0; i < s.count; ++i) tmp[i] = dtype == WM_BF16 ? f32_to_bf16_host(w[off + i]) : f32_to_f16_host(w[off + i]);
+            ok = ok && fwrite(tmp.data(), 2, s.count, o) == s.count;
+        } else {
+            ok = ok && fwrite(w.data() + off, 4, s.count, o) == s.count;
+        }
+        off += s.count;
+    }
+    ok = (fclose(o) == 0) && ok;
+    return ok ? 0 : fail(WM_E_IO, "write error on %s", v2_path);
+}
+
+// Reads a v1 or v2 file into an fp32 image of wm_weight_count(dims) floats, validating size / header against dims.
+extern "C" int wm_weights_read(const char* path, const wm_dims* dims, float* out) {
+    if (!path || !dims || !out) return fail(WM_E_ARG, "null argument");
+    const size_t n = wm_synth_count(dims);
     FILE* f = fopen(path, "rb");
     if (!f) return fail(WM_E_IO, "cannot open %s", path);
     fseek(f, 0, SEEK_END);
-    long sz = ftell(f);
+    const long sz = ftell(f);
     fseek(f, 0, SEEK_SET);
-    const size_t want = wm_synth_count(&cfg->dims) * 4;
-    if (sz < 0 || (size_t)sz != want) {
+    WmV2Header h{};
+    const bool v2 = sz >= (long)sizeof h && fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, WM_V2_MAGIC, 8) == 0;
+    if (!v2) {
+        fseek(f, 0, SEEK_SET);
+        if (sz < 0 || (size_t)sz != n * 4) {
+            fclose(f);
+            return fail(WM_E_SIZE, "%s is %ld bytes, this config needs %zu", path, sz, n * 4);
+        }
+        const size_t got = fread(out, 4, n, f);
         fclose(f);
-        return fail(WM_E_SIZE, "%s is %ld bytes, this config needs %zu", path, sz, want);
+        return got == n ? 0 : fail(WM_E_IO, "short read on %s", path);
     }
-    std::vector<float> buf(want / 4);
-    size_t got = fread(buf.data(), 1, want, f);
+    int rc = 0;
+    if (h.version != 2 || h.matrix_dtype > 2)
+        rc = fail(WM_E_SIZE, "%s: unsupported v2 header (version %u, dtype %u)", path, h.version, h.matrix_dtype);
+    else if (memcmp(h.dims, dims, sizeof h.dims) != 0)
+        rc = fail(WM_E_SIZE, "%s was written for other dims (d_model %d, layers %d, vocab %d)", path, h.dims[0], h.dims[2], h.dims[7]);
+    else if (h.payload_bytes != v2_payload_bytes(dims, (int)h.matrix_dtype, h.flags) || (size_t)sz != sizeof h + h.payload_bytes)
+        rc = fail(WM_E_SIZE, "%s: payload size does not match its header", path);
+    if (!rc) {
+        std::vector<TensorSpan> t;
+        wm_synth_walk(dims, collect_tensor, &t);
+        size_t off = 0;
+        std::vector<uint16_t> tmp;
+        for (auto& s : t) {
+            if (v2_is_matrix(s.kind, h.flags) && h.matrix_dtype != WM_F32) {
+                tmp.resize(s.count);
+                if (fread(tmp.data(), 2, s.count, f) != s.count) {
+                    rc = fail(WM_E_IO, "short read on %s", path);
+                    break;
+                }
+                for (size_t i = 0; i < s.count; ++i) out[off + i] = h.matrix_dtype == WM_BF16 ? bf16_to_f32_host(tmp[i]) : f16_to_f32_host(tmp[i]);
+            } else if (fread(out + off, 4, s.count, f) != s.count) {
+                rc = fail(WM_E_IO, "short read on %s", path);
+                break;
+            }
+            off += s.count;
+        }
+    }
     fclose(f);
-    if (got != want) return fail(WM_E_IO, "short read on %s", path);
+    return rc;
+}
+
+extern "C" int wm_model_load(const char* path, const wm_config* cfg, int device, wm_model** out) {
+    if (!path || !cfg || !out) return fail(WM_E_ARG, "null argument");
+    WMCHK(check_cfg(cfg));
+    std::vector<float> buf(wm_synth_count(&cfg->dims));
+    WMCHK(wm_weights_read(path, &cfg->dims, buf.data()));
     return wm_model_load_memory(buf.data(), buf.size(), cfg, device, out);
 }
 
