@@ -651,7 +651,13 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
             ln.nb = std::max(0, std::min(per, B - b0));
             b0 += ln.nb;
             ln.ctl = s->ctl.as<StepCtl>() + 1 + i;
-            hipError_t e = hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking);
+            // decode launches are latency-critical (34 dependent sub-5-us kernels per token); the encoder stream carries
+            // throughput work.  WM_DEC_PRIORITY=1 puts the lane streams on the highest HIP stream priority.
+            int lo_p = 0, hi_p = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+            static const bool prio = getenv("WM_DEC_PRIORITY") != nullptr;
+            hipError_t e = prio ? hipStreamCreateWithPriority(&ln.st, hipStreamNonBlocking, hi_p)
+                                : hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.done, hipEventDisableTiming);
             if (e != hipSuccess) {
                 wm_state_free(s);
