@@ -3,7 +3,7 @@
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from whisper_mojo_amd import WhisperConfig, _lib, DT_BF16
+from whisper_mojo_amd import WhisperConfig, _lib, DT_BF16, DT_F32
 from whisper_mojo_amd.loader import WeightLoader
 from whisper_mojo_amd.whisper import Whisper
 L = _lib.lib()
@@ -12,7 +12,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 w = np.empty(cfg.weight_count(), np.float32)
 d = cfg.dims()
 L.wm_synth_weights(C.byref(d), 0, w.ctypes.data_as(C.POINTER(C.c_float)))
-m = Whisper(cfg, compute_dtype=DT_BF16, max_batch=B)
+DT = DT_F32 if os.environ.get('CHAIN_F32') else DT_BF16
+m = Whisper(cfg, compute_dtype=DT, max_batch=B)
 m.load(WeightLoader.from_array(w))
 st = C.c_void_p()
 _lib.check(L.wm_state_new(m._h, B, C.byref(st)))

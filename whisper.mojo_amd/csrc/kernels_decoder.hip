@@ -552,7 +552,10 @@ template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStrea
     constexpr bool FAST = sizeof(TKV) == 2;
     const int LPR = p.H * LPH;
     AttnDecParams q = p;
-    q.rps = 256 / LPR;  // 512-thread workgroups measured no better for the short self-attention sequence (5.3 vs 5.0 us)
+    // rows swept per step.  16-bit K/V: 256 threads (512 measured no better for the short self-attention: 5.3 vs 5.0 us).
+    // fp32 K/V rows are twice as wide (96-128 lanes per row): the latency-bound self-attention takes 512 threads so a
+    // lane's serial key loop stays short (61 keys: 16 -> 7 iterations)
+    q.rps = ((sizeof(TKV) == 4 && p.n_keys < 0) ? 512 : 256) / LPR;
     // block rounded up to whole waves: the spare lanes take no rows (rslot >= RPS) but stay in the DPP groups
     const dim3 grid(p.nsplit, p.B), block((q.rps * LPR + 63) / 64 * 64);
     static const bool nt_off = getenv("WM_NO_NT") != nullptr;
@@ -589,7 +592,15 @@ __global__ void attn_combine_kernel(const float* __restrict__ part_o, const floa
     const float L = wave_sum(wgt * l);
     const float* po = part_o + (size_t)b * nsplit * d + h * 64 + lane;
     float o = 0.f;
-    for (int s = 0; s < nsplit; ++s) o += __shfl(wgt, s, 64) * po[(size_t)s * d];
+    int s = 0;
+    for (; s + 8 <= nsplit; s += 8) {  // 8 independent loads in flight
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = po[(size_t)(s + j) * d];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o += __shfl(wgt, s + j, 64) * v[j];
+    }
+    for (; s < nsplit; ++s) o += __shfl(wgt, s, 64) * po[(size_t)s * d];
     out[(size_t)b * d + h * 64 + lane] = o * (1.0f / L);
 }
 void launch_attn_combine(const float* part_o, const float* part_ml, float* out, int B, int nsplit, int H, int d,

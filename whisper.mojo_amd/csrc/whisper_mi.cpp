@@ -589,10 +589,18 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
     s->m = m;
     s->B = B;
     s->Bc = std::min(B, m->enc_chunk);
-    // key chunks per utterance for the cross-attention kernel: independent of B so that an utterance's result does not
-    // depend on how it was batched (bitwise batch invariance); WM_NSPLIT overrides for tuning
-    s->nsplit = std::max((int)((T + 511) / 512), (int)((T + 124) / 125));
-    if (const char* e = getenv("WM_NSPLIT")) s->nsplit = std::max((int)((T + 511) / 512), atoi(e));
+    // key chunks per utterance for the cross-attention kernel: a function of the MODEL's max_batch, never of this call's
+    // B, so that an utterance's result does not depend on how it was batched (bitwise batch invariance within a model).
+    // Aim for >= 768 workgroups at full batch: 12 chunks at max_batch 64, up to 48 for small-batch / latency models
+    // (B = 1: 12.1 -> 4 us per launch).  WM_NSPLIT overrides for tuning.
+    {
+        const int min_split = (int)((T + 511) / 512);
+        int ns = (768 + m->cfg.max_batch - 1) / m->cfg.max_batch;
+        ns = std::max(12, std::min(48, ns));
+        ns = std::max(min_split, std::min(ns, (int)((T + 31) / 32)));
+        if (const char* e = getenv("WM_NSPLIT")) ns = std::max(min_split, std::min(64, atoi(e)));
+        s->nsplit = ns;
+    }
     s->out_stride = OUT_STRIDE_MAX;
     const size_t Bc = s->Bc;
     const size_t Mp = (Bc * T + 127) / 128 * 128 + 128;  // padded rows: tail tiles read (never store) past M
