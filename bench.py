@@ -103,7 +103,11 @@ def main():
     from whisper_mojo_amd.whisper import Whisper
     import ctypes as C
 
-    rank, local, world = wdist.init_from_env("nccl")
+    # rehearsal knobs (not used by the driver): WM_BENCH_BACKEND=gloo + WM_BENCH_SINGLE_DEVICE=1 run N ranks on ONE GPU
+    backend = os.environ.get("WM_BENCH_BACKEND", "nccl")
+    rank, local, world = wdist.init_from_env(backend)
+    if os.environ.get("WM_BENCH_SINGLE_DEVICE"):
+        local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     cfg_name, B, cdt, kdt = WORKLOADS[args.workload]
@@ -170,8 +174,9 @@ def main():
     out = run_steps(args.steps)
     sync()
     dt = time.perf_counter() - t0
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     assert out is not None and len(out) == total and all(len(o) == stride for o in out)
@@ -189,7 +194,7 @@ def main():
         seq_dt = time.perf_counter() - t1
         args.no_pipeline = saved
         if world > 1:
-            t = torch.tensor([seq_dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([seq_dt], dtype=torch.float64, device=red_dev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             seq_dt = float(t.item())
     if rank == 0:
