@@ -153,6 +153,7 @@ struct wm_state {
     };
     std::vector<Lane> lanes;
     hipEvent_t enc_done = nullptr;
+    hipStream_t enc_stream = nullptr;  // stream the pending pass's encoder was enqueued on
     StepCtl* h_ctl = nullptr;  // pinned host copy of the control blocks (finish polling)
     int graph_eot = 0, graph_ignore = 0;
     bool graphs_valid = false;
@@ -704,7 +705,7 @@ extern "C" int wm_state_len(const wm_state* s) { return s ? s->host_len : -1; }
 // ---- encoder: whisper.mojo:71-99 ------------------------------------------------------------------------------------
 static void* off_bytes(const DevBuf& b, size_t bytes) { return (char*)b.p + bytes; }
 
-static int cross_kv_chunk(wm_model* m, wm_state* s, int c0, int bc) {
+static int cross_kv_chunk(wm_model* m, wm_state* s, int c0, int bc, hipStream_t st) {
     // cross K/V for utterances [c0, c0+bc) from enc_t (rows 0..bc*T): layers.mojo:150-154, all layers in one GEMM
     const wm_dims& c = m->cfg.dims;
     const size_t d = c.d_model, T = c.n_audio_ctx;
@@ -721,15 +722,14 @@ static int cross_kv_chunk(wm_model* m, wm_state* s, int c0, int bc) {
     p.bias = m->cross_kv_b.as<float>();
     p.group_n = c.d_model;
     p.group_stride = (long)((size_t)s->B * T * d);
-    gemm_dispatch(m->cfg.compute_dtype, m->cfg.kv_dtype, p, 1, m->stream);
+    gemm_dispatch(m->cfg.compute_dtype, m->cfg.kv_dtype, p, 1, st);
     return 0;
 }
 
-static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B) {
+static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hipStream_t st) {
     const wm_dims& c = m->cfg.dims;
     const int T = m->cfg.compute_dtype;
     const size_t d = c.d_model, L = 2 * (size_t)c.n_audio_ctx, NT = c.n_audio_ctx, ts = dt_size(T);
-    hipStream_t st = m->stream;
     const float scale = 1.0f / sqrtf(64.0f);
     for (int c0 = 0; c0 < B; c0 += s->Bc) {
         const int bc = std::min(s->Bc, B - c0);
@@ -834,7 +834,7 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B) {
         }
         float* encf = s->enc_f.as<float>() + (size_t)c0 * NT * d;
         DISPATCH_DT(T, TT, launch_layernorm_rows<TT>(s->x.as<float>(), m->enc_ln_g.as<float>(), m->enc_ln_b.as<float>(), s->enc_t.p, encf, M, c.d_model, 1e-5f, st));
-        WMCHK(cross_kv_chunk(m, s, c0, bc));
+        WMCHK(cross_kv_chunk(m, s, c0, bc, st));
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -858,7 +858,7 @@ extern "C" int wm_encode(wm_model* m, wm_state* s, const float* mel, int mel_on_
         HIPCHK(hipMemcpyAsync(s->mel_dev.p, mel, (size_t)B * c.n_mels * 2 * c.n_audio_ctx * 4, hipMemcpyHostToDevice, m->stream));
         mel_dev = s->mel_dev.as<float>();
     }
-    WMCHK(run_encoder(m, s, mel_dev, B));
+    WMCHK(run_encoder(m, s, mel_dev, B, m->stream));
     s->has_enc = s->has_cross = true;
     s->last_mel = mel_dev;
     if (enc_out) HIPCHK(hipMemcpyAsync(enc_out, s->enc_f.p, (size_t)B * c.n_audio_ctx * c.d_model * 4, hipMemcpyDeviceToHost, m->stream));
@@ -877,7 +877,7 @@ extern "C" int wm_state_set_encoder_output(wm_model* m, wm_state* s, const float
     for (int c0 = 0; c0 < B; c0 += s->Bc) {
         const int bc = std::min(s->Bc, B - c0);
         DISPATCH_DT(m->cfg.compute_dtype, TT, launch_convert<TT>(s->enc_f.as<float>() + (size_t)c0 * NT * d, s->enc_t.p, (size_t)bc * NT * d, m->stream));
-        WMCHK(cross_kv_chunk(m, s, c0, bc));
+        WMCHK(cross_kv_chunk(m, s, c0, bc, m->stream));
     }
     HIPCHK(hipStreamSynchronize(m->stream));
     s->has_enc = s->has_cross = true;
@@ -1127,7 +1127,7 @@ extern "C" int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, i
 // utterance has emitted eot; the pipelined one enqueues all max_loop steps (finished utterances stop recording).
 static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, bool allow_poll) {
     const int B = s->B;
-    HIPCHK(hipEventRecord(s->enc_done, m->stream));  // encoder + cross K/V of this state
+    HIPCHK(hipEventRecord(s->enc_done, s->enc_stream ? s->enc_stream : m->stream));  // encoder + cross K/V of this state
     static const bool trace_phase = getenv("WM_TRACE_HOST") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
     static const bool no_graph = getenv("WM_NO_GRAPH") != nullptr;
@@ -1266,14 +1266,23 @@ static int submit_on(wm_model* m, wm_state** slot, const float* mel, int mel_on_
     }
     wm_state* s = *slot;
     if (s->pending) return fail(WM_E_STATE, "this slot still holds a pass that was not waited for");
-    WMCHK(wm_state_reset(s));
+    // stream of this pass's encoder: the model stream (shared by all slots), or — WM_ENC_ON_LANE — the slot's own decode stream
+    static const bool enc_on_lane = getenv("WM_ENC_ON_LANE") != nullptr;
+    hipStream_t est = enc_on_lane ? s->lanes[0].st : m->stream;
+    s->has_enc = s->has_cross = false;
+    s->host_len = 0;
+    if (est != m->stream) {  // whatever produced the mel on the model stream (the log-mel front end) comes first
+        HIPCHK(hipEventRecord(s->enc_done, m->stream));
+        HIPCHK(hipStreamWaitEvent(est, s->enc_done, 0));
+    }
     const float* mel_dev = mel;
     if (!mel_on_device) {
-        HIPCHK(hipMemcpyAsync(s->mel_dev.p, mel, (size_t)B * c.n_mels * 2 * c.n_audio_ctx * 4, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(s->mel_dev.p, mel, (size_t)B * c.n_mels * 2 * c.n_audio_ctx * 4, hipMemcpyHostToDevice, est));
         mel_dev = s->mel_dev.as<float>();
     }
     const auto tt0 = std::chrono::steady_clock::now();
-    WMCHK(run_encoder(m, s, mel_dev, B));
+    WMCHK(run_encoder(m, s, mel_dev, B, est));
+    s->enc_stream = est;
     s->has_enc = s->has_cross = true;
     s->last_mel = mel_dev;
     if (getenv("WM_TRACE_HOST")) {
@@ -1632,9 +1641,9 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
         return 0;
     } else if (which == WM_KERNEL_ENCODER) {
         if (!s->last_mel) return fail(WM_E_STATE, "no mel was encoded into this state");
-        WMCHK(run_encoder(m, s, s->last_mel, s->B));
+        WMCHK(run_encoder(m, s, s->last_mel, s->B, st));
         HIPCHK(hipEventRecord(e0, st));
-        for (int i = 0; i < reps; ++i) WMCHK(run_encoder(m, s, s->last_mel, s->B));
+        for (int i = 0; i < reps; ++i) WMCHK(run_encoder(m, s, s->last_mel, s->B, st));
         HIPCHK(hipEventRecord(e1, st));
     } else {
         return fail(WM_E_ARG, "unknown kernel id %d", which);
