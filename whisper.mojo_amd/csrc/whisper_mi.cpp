@@ -604,7 +604,7 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
     }
     s->out_stride = OUT_STRIDE_MAX;
     const size_t Bc = s->Bc;
-    const size_t Mp = (Bc * T + 127) / 128 * 128 + 128;  // padded rows: tail tiles read (never store) past M
+    const size_t Mp = (Bc * T + 255) / 256 * 256 + 256;  // padded rows: tail tiles (up to 256 rows) read, never store, past M
     int rc = 0;
     auto A = [&](DevBuf& b, size_t bytes, bool zero = false) {
         if (!rc) rc = b.alloc(bytes, zero);
@@ -1378,7 +1378,7 @@ static int frontend_init(wm_model* m) {
     WMCHK(m->fe.band.alloc(band.size() * 4));
     HIPCHK(hipMemcpy(m->fe.band.p, band.data(), band.size() * 4, hipMemcpyHostToDevice));
     const size_t ch = std::min(maxB, m->fe.chunk);
-    const size_t rows = (ch * n_frames + 127) / 128 * 128 + 128;
+    const size_t rows = (ch * n_frames + 255) / 256 * 256 + 256;
     WMCHK(m->fe.pcm.alloc((size_t)maxB * N * 4, true));
     WMCHK(m->fe.lens.alloc((size_t)maxB * 4, true));
     WMCHK(m->fe.frames.alloc(rows * 416 * 4, true));
