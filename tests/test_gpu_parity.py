@@ -60,6 +60,18 @@ def test_op_matmul(hip, oracle_mod, M, N, K):
         assert np.abs(out - ref).max() < 1e-5 * K ** 0.5 * 8
 
 
+def test_op_matmul_wide_ragged_repeat(hip, oracle_mod):
+    """N >= 1024 takes two 16-column tiles per workgroup; with round_up(N, 16) % 32 == 16 the last workgroup has only one.
+    (A store of the missing tile would race with the next row's first columns — repeat to give a race the chance.)"""
+    from whisper_mojo_amd import whisper_tensor as wt
+    A, B = rng.standard_normal((9, 256), np.float32), rng.standard_normal((1037, 256), np.float32)
+    ref = oracle_mod.matmul(A, B, None)
+    for _ in range(20):
+        out = wt.Tensor(9, 1037)
+        wt.matmul(out, A, B, None)
+        assert np.abs(out - ref).max() < 1e-3
+
+
 def test_op_matmul_bf16_rounding(hip):
     """16-bit operand mode = exact products of the rounded operands (fp32 accumulate)."""
     import torch

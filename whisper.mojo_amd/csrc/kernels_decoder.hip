@@ -61,7 +61,8 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
 
     // epilogue operands (wave t finishes column tile t)
     const int eb = b0 + r16, en = n0 + (w < NT ? w : 0) * 16 + g * 4;
-    const bool epi = w < NT && eb < p.B;
+    // a second column tile that starts past the (16-padded) width does not exist: storing it would land in the next row
+    const bool epi = w < NT && eb < p.B && n0 + (w < NT ? w : 0) * 16 < ((p.N + 15) & ~15);
     float bias4[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 res4 = f32x4{0.f, 0.f, 0.f, 0.f};
     int cache_row = 0;

@@ -48,6 +48,78 @@ void launch_mel_transpose_pad(const float* mel, void* out, int B, int C, int L, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Shared GEMM epilogue.  acc[j][i][r] = C[m0 + 16i + r16][n0 + 16j + 4g + r] for a wave's 64x64 sub-tile.
+// out = act(acc + bias) + pos + residual.  Every operand the epilogue reads (bias, positional rows, residual rows) is
+// requested up front, before anything is waited for: 16 dependent load->wait->store rounds per wave were the longest
+// phase of a K=384 tile.  A 64-wide wave tile never straddles a column group (group_n = d_model = 64·heads).
+template <typename TO, bool FASTG>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], int m0, int n0, int bz, int r16, int g) {
+    TO* Cb = (TO*)p.C + (size_t)bz * p.strideC;
+    int nc = n0 + g * 4;  // column inside the group
+    if (p.group_n > 0) {
+        const int grp = n0 / p.group_n;
+        Cb += (size_t)grp * p.group_stride;
+        nc -= grp * p.group_n;
+    }
+    f32x4 bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + j * 16 + g * 4);
+    }
+    bool valid[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) valid[i] = m0 + i * 16 + r16 < p.M;
+    f32x4 ex[4][4];  // post-activation addend: pos + residual
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ex[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.residual) {
+        const float* Rb = p.residual + (size_t)bz * p.strideR + n0 + g * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (valid[i]) {
+                const float* rr = Rb + (size_t)(m0 + i * 16 + r16) * p.ldr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ex[i][j] = *reinterpret_cast<const f32x4*>(rr + j * 16);
+            }
+    }
+    if (p.pos) {
+        const float* Pb = p.pos + n0 + g * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (valid[i]) {
+                const float* pr = Pb + (size_t)(m0 + i * 16 + r16) * p.N;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ex[i][j] += *reinterpret_cast<const f32x4*>(pr + j * 16);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!valid[i]) continue;
+        TO* crow = Cb + (size_t)(m0 + i * 16 + r16) * p.ldc + nc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = acc[j][i] + bv[j];
+            if (p.act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = FASTG ? gelu_fast(v[r], p.gelu_mode) : gelu_f(v[r], p.gelu_mode);
+            }
+            v += ex[i][j];
+            if constexpr (sizeof(TO) == 4) {
+                *reinterpret_cast<f32x4*>((float*)crow + j * 16) = v;
+            } else {
+                typedef __attribute__((ext_vector_type(4))) TO to4;
+                to4 o = {from_f32<TO>(v[0]), from_f32<TO>(v[1]), from_f32<TO>(v[2]), from_f32<TO>(v[3])};
+                *reinterpret_cast<to4*>(crow + j * 16) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // C[M,N] = A[M,K]·W[N,K]ᵀ with a fused epilogue.  Both operands are K-contiguous ("NT"), which is what the
 // reference's HF-layout weights give (whisper_tensor.mojo:151: B is [out,in]) and what MFMA fragments want.
 // 128x128 tile / 256 threads; wave (wm,wn) owns 64x64 = 4x4 MFMA 16x16 accumulators; K step 32.
@@ -88,38 +160,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
             for (int i = 0; i < 4; ++i) acc[j][i] = mma32(b[j], a[i], acc[j][i]);
     }
 
-    // epilogue: acc[j][i][r] = C[m0 + 16i + r16][n0 + 16j + 4g + r]
-    TO* Cb = (TO*)p.C + (size_t)blockIdx.z * p.strideC;
-    const float* Rb = p.residual ? p.residual + (size_t)blockIdx.z * p.strideR : nullptr;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + i * 16 + r16;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + j * 16 + g * 4;
-            f32x4 v = acc[j][i];
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (p.act) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], p.gelu_mode);
-            }
-            if (p.pos) v += *reinterpret_cast<const f32x4*>(p.pos + (size_t)m * p.N + n);
-            if (Rb) v += *reinterpret_cast<const f32x4*>(Rb + (size_t)m * p.ldr + n);
-            size_t off;
-            if (p.group_n > 0)
-                off = (size_t)(n / p.group_n) * p.group_stride + (size_t)m * p.ldc + (n % p.group_n);
-            else
-                off = (size_t)m * p.ldc + n;
-            if constexpr (sizeof(TO) == 4) {
-                *reinterpret_cast<f32x4*>((float*)Cb + off) = v;
-            } else {
-                typedef __attribute__((ext_vector_type(4))) TO to4;
-                to4 o = {from_f32<TO>(v[0]), from_f32<TO>(v[1]), from_f32<TO>(v[2]), from_f32<TO>(v[3])};
-                *reinterpret_cast<to4*>(Cb + off) = o;
-            }
-        }
-    }
+    gemm_epilogue<TO, false>(p, acc, m0, n0, blockIdx.z, r16, g);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -148,8 +189,21 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmParams p) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int r16 = lane & 15, g = lane >> 4;
-    const int bm = blockIdx.y * 128, bn = blockIdx.x * 128;
-    const T* A = (const T*)p.A + (size_t)blockIdx.z * p.strideA + (size_t)bm * p.lda;
+    // XCD-aware tile order: the hardware deals workgroups round-robin to the 8 XCDs (private L2 each); give XCD x a
+    // contiguous run of logical tiles (column tiles of one row tile adjacent) so an A tile is fetched into one L2 once.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_remap) {
+        const int G = gridDim.x * gridDim.y * gridDim.z;
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int x = lin & 7, q = lin >> 3, per = G >> 3, rem = G & 7;
+        const int t = x * per + (x < rem ? x : rem) + q;
+        bx = t % gridDim.x;
+        const int u = t / gridDim.x;
+        by = u % gridDim.y;
+        bz = u / gridDim.y;
+    }
+    const int bm = by * 128, bn = bx * 128;
+    const T* A = (const T*)p.A + (size_t)bz * p.strideA + (size_t)bm * p.lda;
     const T* W = (const T*)p.W + (size_t)bn * p.ldw;
     f32x4 acc[4][4];
 #pragma unroll
@@ -188,39 +242,7 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmParams p) {
         cur ^= 1;
     }
 
-    // epilogue: acc[j][i][r] = C[m0 + 16i + r16][n0 + 16j + 4g + r]
-    const int m0 = bm + wm * 64, n0 = bn + wn * 64;
-    TO* Cb = (TO*)p.C + (size_t)blockIdx.z * p.strideC;
-    const float* Rb = p.residual ? p.residual + (size_t)blockIdx.z * p.strideR : nullptr;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + i * 16 + r16;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + j * 16 + g * 4;
-            f32x4 v = acc[j][i];
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (p.act) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r], p.gelu_mode);
-            }
-            if (p.pos) v += *reinterpret_cast<const f32x4*>(p.pos + (size_t)m * p.N + n);
-            if (Rb) v += *reinterpret_cast<const f32x4*>(Rb + (size_t)m * p.ldr + n);
-            size_t off;
-            if (p.group_n > 0)
-                off = (size_t)(n / p.group_n) * p.group_stride + (size_t)m * p.ldc + (n % p.group_n);
-            else
-                off = (size_t)m * p.ldc + n;
-            if constexpr (sizeof(TO) == 4) {
-                *reinterpret_cast<f32x4*>((float*)Cb + off) = v;
-            } else {
-                typedef __attribute__((ext_vector_type(4))) TO to4;
-                to4 o = {from_f32<TO>(v[0]), from_f32<TO>(v[1]), from_f32<TO>(v[2]), from_f32<TO>(v[3])};
-                *reinterpret_cast<to4*>(Cb + off) = o;
-            }
-        }
-    }
+    gemm_epilogue<TO, true>(p, acc, bm + wm * 64, bn + wn * 64, bz, r16, g);
 }
 
 template <typename T, typename TO> void launch_gemm_nt(const GemmParams& p, int batch, hipStream_t st) {
@@ -228,7 +250,10 @@ template <typename T, typename TO> void launch_gemm_nt(const GemmParams& p, int 
     static const bool no_lds = getenv("WM_GEMM_DIRECT") != nullptr;
     if constexpr (sizeof(T) == 2) {
         if (!no_lds && (p.K & 63) == 0) {
-            hipLaunchKernelGGL((gemm_nt_lds_kernel<T, TO>), grid, dim3(256), 0, st, p);
+            static const bool no_remap = getenv("WM_GEMM_NOXCD") != nullptr;
+            GemmParams q = p;
+            q.xcd_remap = !no_remap;
+            hipLaunchKernelGGL((gemm_nt_lds_kernel<T, TO>), grid, dim3(256), 0, st, q);
             return;
         }
     }

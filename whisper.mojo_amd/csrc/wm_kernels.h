@@ -27,6 +27,7 @@ struct GemmParams {
     int gelu_mode;
     int group_n;  // >0: column n goes to C + (n/group_n)*group_stride + m*ldc + n%group_n  (cross-K/V scatter)
     long group_stride;
+    int xcd_remap;  // set by the launcher (LDS-staged kernel only)
 };
 template <typename T> void launch_mel_transpose_pad(const float* mel, void* out, int B, int C, int L, int Cp, hipStream_t st);
 template <typename T, typename TO> void launch_gemm_nt(const GemmParams& p, int batch, hipStream_t st);
