@@ -243,6 +243,7 @@ def main():
             log("cpu baseline (oracle) ...")
             res["cpu_baseline"] = cpu_baseline(cfg, weights, mel_host[0], DECODE_STEPS)
         print(json.dumps(res), flush=True)
+    model.close()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

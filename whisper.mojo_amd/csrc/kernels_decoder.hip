@@ -12,6 +12,16 @@
 namespace wm {
 
 // ------------------------------------------------------------------------------------------------------------
+// Developer timeline: ts[0] = entry count, then (tag, 100 MHz clock) pairs; tag = owner id << 8 | kind
+// (0 cross-attention start, 1 merge start, 2 logits start, 3 argmax start).  Off (null) outside WM_TRACE_EVENTS=<file>.
+__device__ __forceinline__ void ts_put(long long* ts, int id, int kind) {
+    const unsigned long long i = atomicAdd((unsigned long long*)ts, 1ull);
+    if (i < (1ull << 20)) {
+        ts[1 + 2 * i] = ((long long)id << 8) | kind;
+        ts[2 + 2 * i] = (long long)wall_clock64();
+    }
+}
+
 // x[b] = token_emb[tok[b]] + pos_emb[pos[b]]      (whisper.mojo:141-149)
 __global__ void dec_embed_kernel(const float* __restrict__ tok_emb, const float* __restrict__ pos_emb,
                                  const int* __restrict__ tok, const int* __restrict__ pos, float* __restrict__ x, int d) {
@@ -58,7 +68,6 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
         wp[t] = (const TW*)p.W + (size_t)wrow * p.K + g * 8;
     }
     const float* xp = p.x + (size_t)xrow * p.ldx + g * 8;
-
     // epilogue operands (wave t finishes column tile t)
     const int eb = b0 + r16, en = n0 + (w < NT ? w : 0) * 16 + g * 4;
     // a second column tile that starts past the (16-padded) width does not exist: storing it would land in the next row
@@ -234,6 +243,7 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int row0 = blockIdx.y * NRB * 16;
+    if (p.ts && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ts_put(p.ts, p.ts_id, 2);
     const int nrows = min(NRB * 16, p.B - row0);
     const int n0 = blockIdx.x * 128 + w * 32;
     const TW* wp[2];
@@ -434,6 +444,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecParams p) {
     __shared__ float s_ml[512][2];
     __shared__ float s_red[512 * EPL];
     const int b = blockIdx.y, split = blockIdx.x;
+    if (p.ts && NT && b == 0 && split == 0 && threadIdx.x == 0) ts_put(p.ts, p.ts_id, 0);
     const int LPR = p.H * LPH;
     const int RPS = p.rps;  // key rows swept per step = active threads / LPR
     const int len = p.n_keys >= 0 ? p.n_keys : p.ctl->len + 1;
@@ -580,8 +591,9 @@ template void launch_attn_decode<f16>(const AttnDecParams&, hipStream_t);
 // One wave per (utterance, head): lane s owns chunk s's (m, l) — one exp per chunk, not per element — and the
 // weights reach the 64 output lanes by wave broadcast.  nsplit <= 64.
 __global__ void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                    float* __restrict__ out, int nsplit, int H, int d) {
+                                    float* __restrict__ out, int nsplit, int H, int d, long long* ts, int ts_id) {
     const int b = blockIdx.x, lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+    if (ts && b == 0 && threadIdx.x == 0) ts_put(ts, ts_id, 1);
     float m = -1e30f, l = 0.f;
     if (lane < nsplit) {
         const float* ml = part_ml + (((size_t)b * nsplit + lane) * H + h) * 2;
@@ -605,8 +617,8 @@ __global__ void attn_combine_kernel(const float* __restrict__ part_o, const floa
     out[(size_t)b * d + h * 64 + lane] = o * (1.0f / L);
 }
 void launch_attn_combine(const float* part_o, const float* part_ml, float* out, int B, int nsplit, int H, int d,
-                         hipStream_t st) {
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(B), dim3(64 * H), 0, st, part_o, part_ml, out, nsplit, H, d);
+                         hipStream_t st, long long* ts, int ts_id) {
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(B), dim3(64 * H), 0, st, part_o, part_ml, out, nsplit, H, d, ts, ts_id);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -702,6 +714,7 @@ __device__ __forceinline__ void argmax_partials(const float* pv, const int* pi, 
 }
 __global__ __launch_bounds__(1024) void argmax_step_kernel(ArgmaxParams p) {
     const int b = blockIdx.x;
+    if (p.ts && b == 0 && threadIdx.x == 0) ts_put(p.ts, p.ts_id, 3);
     float best;
     int idx;
     if (p.pval)

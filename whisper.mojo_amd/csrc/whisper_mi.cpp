@@ -46,6 +46,47 @@ static int fail(int code, const char* fmt, ...) {
 
 extern "C" const char* wm_last_error(void) { return g_err.c_str(); }
 
+// Developer timeline (WM_TRACE_EVENTS=1): HIP events recorded on the library's streams at pass / phase boundaries and
+// printed, sorted on the GPU clock, when the model is freed.  The profiler serialises concurrent queues; events do not.
+struct TraceMark {
+    hipEvent_t ev;
+    std::string label;
+};
+static std::vector<TraceMark> g_trace;
+static bool trace_events_on() {
+    static const bool on = getenv("WM_TRACE_EVENTS") != nullptr;
+    return on;
+}
+static void trace_mark(hipStream_t st, const char* fmt, ...) {
+    if (!trace_events_on() || g_trace.size() > 200000) return;
+    char buf[128];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, st);
+    g_trace.push_back({e, buf});
+}
+static void trace_dump() {
+    if (g_trace.empty()) return;
+    (void)hipDeviceSynchronize();
+    std::vector<std::pair<float, std::string>> rows;
+    for (auto& t : g_trace) {
+        float ms = 0.f;
+        const hipError_t e = hipEventElapsedTime(&ms, g_trace[0].ev, t.ev);
+        if (e == hipSuccess)
+            rows.push_back({ms, t.label});
+        else
+            fprintf(stderr, "[wm-trace] %s: %s\n", t.label.c_str(), hipGetErrorString(e));
+    }
+    for (auto& t : g_trace) (void)hipEventDestroy(t.ev);
+    g_trace.clear();
+    std::sort(rows.begin(), rows.end());
+    for (auto& r : rows) fprintf(stderr, "[wm-trace] %10.3f ms  %s\n", r.first, r.second.c_str());
+}
+
 static size_t dt_size(int dt) { return dt == WM_F32 ? 4 : 2; }
 static inline uint16_t f32_to_bf16_host(float f) {
     uint32_t u;
@@ -122,6 +163,7 @@ struct wm_model {
     std::vector<DecLayer> dec;
     DevBuf dec_ln_g, dec_ln_b;
     DevBuf cross_kv_w, cross_kv_b;  // [L*2*d][d] rows: layer-major, K then V
+    DevBuf ts_buf;     // developer timeline (WM_TRACE_EVENTS=<file>): count + (tag, clock) pairs
     // log-mel front end (lazy): constants + scratch sized for max_batch utterances
     struct Frontend {
         bool ready = false;
@@ -158,6 +200,7 @@ struct wm_state {
     int graph_eot = 0, graph_ignore = 0;
     bool graphs_valid = false;
     bool pending = false;   // a submitted pass has not been waited for yet
+    int trace_id = 1;       // slot + 1: tags this state's entries in the developer timeline
     int pend_total = 0;     // ids per utterance of the pending pass
     const float* last_mel = nullptr;  // device pointer of the last encoded batch (bench replays the encoder on it)
     // encoder arena (sized for Bc utterances)
@@ -263,6 +306,22 @@ static std::vector<float> conv_relayout(const float* w, int co, int ci, int cip)
 extern "C" void wm_state_free(wm_state* s);
 
 extern "C" void wm_model_free(wm_model* m) {
+    if (m && trace_events_on()) {
+        trace_dump();
+        {
+            const char* path = getenv("WM_TRACE_EVENTS");
+            if (m->ts_buf.p && path) {
+                std::vector<long long> h((2u << 20) + 1);
+                if (hipMemcpy(h.data(), m->ts_buf.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                    if (FILE* f = fopen(path, "w")) {
+                        const long long n = std::min<long long>(h[0], 1ll << 20);
+                        for (long long i = 0; i < n; ++i) fprintf(f, "%lld %lld %lld\n", h[1 + 2 * i] >> 8, h[1 + 2 * i] & 255, h[2 + 2 * i]);
+                        fclose(f);
+                    }
+                }
+            }
+        }
+    }
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->cached) wm_state_free(m->cached);
@@ -377,6 +436,7 @@ static int model_build(wm_model* m, const float* w) {
     WMCHK(upload(m->dec_ln_b, r.take(d), d, WM_F32));
     WMCHK(upload(m->cross_kv_w, ckv.data(), ckv.size(), T));
     WMCHK(upload(m->cross_kv_b, ckvb.data(), ckvb.size(), WM_F32));
+    if (trace_events_on() && strchr(getenv("WM_TRACE_EVENTS"), '/')) WMCHK(m->ts_buf.alloc(((2u << 20) + 1) * 8, true));
     if (r.off != wm_synth_count(&c)) return fail(WM_E_SIZE, "internal: consumed %zu floats, expected %zu", r.off, wm_synth_count(&c));
     return 0;
 }
@@ -919,6 +979,8 @@ static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v)
     a.H = c.n_heads;
     a.d = c.d_model;
     a.B = v.nb;
+    a.ts = (long long*)m->ts_buf.p;
+    a.ts_id = s->trace_id;
     attn_decode_dispatch(m->cfg.kv_dtype, a, v.st);
 }
 
@@ -1016,7 +1078,7 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
         // (merging the chunk partials inside the projection's prologue was measured 14 us per layer SLOWER than this
         // 3 us launch: 96 workgroups each re-reading 295 KB of partials)
         launch_attn_combine(s->part_o.as<float>() + (size_t)v.b0 * s->nsplit * d, s->part_ml.as<float>() + (size_t)v.b0 * s->nsplit * c.n_heads * 2,
-                            dattn, B, s->nsplit, c.n_heads, c.d_model, st);
+                            dattn, B, s->nsplit, c.n_heads, c.d_model, st, (long long*)m->ts_buf.p, s->trace_id);
         proj_residual(dattn, c.d_model, w.co_w, w.co_b);
         {  // LN2 -> fc1 + GELU
             DecLinearParams p{};
@@ -1053,6 +1115,8 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
         p.amax_idx = s->amax_idx.as<int>() + (size_t)v.b0 * s->npart;
         p.amax_stride = s->npart;
         p.amax_mask = mask;
+        p.ts = (long long*)m->ts_buf.p;
+        p.ts_id = s->trace_id;
         DISPATCH_DT(T, TT, launch_dec_logits<TT>(p, st));
     }
 }
@@ -1077,6 +1141,8 @@ static ArgmaxParams argmax_params(wm_model* m, wm_state* s, const DecView& v, bo
     a.ignore_eot = ignore_eot;
     a.advance = advance ? 1 : 0;
     a.pos = s->pos.as<int>() + v.b0;
+    a.ts = (long long*)m->ts_buf.p;
+    a.ts_id = s->trace_id;
     return a;
 }
 
@@ -1156,6 +1222,7 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
     for (auto& ln : s->lanes) {
         const DecView v{ln.b0, ln.nb, ln.st, ln.ctl};
         HIPCHK(hipStreamWaitEvent(v.st, s->enc_done, 0));
+        trace_mark(v.st, "state %p lane %d decode start", (void*)s, v.b0);
         // tokens = prompt (whisper.mojo:187-191, 200-202); finished = 0; control block = 0
         ip.out_tokens = s->out_tokens.as<int>() + (size_t)v.b0 * s->out_stride;
         ip.out_stride = s->out_stride;
@@ -1170,6 +1237,7 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
             decode_core(m, s, v, i == o->n_prompt - 1, false, s->mask_begin.as<float>());
         }
         launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot), v.st);  // :198-203
+        trace_mark(v.st, "state %p lane %d prefill end", (void*)s, v.b0);
         // incremental steps: start_pos = current_len - 1 (reference, :217) or current_len (HF)
         launch_set_step(v.ctl, o->n_prompt, 1, s->pos.as<int>() + v.b0, first_pos, nullptr, 0, v.nb, v.st);
         // steady state: one captured graph per lane = [37 decode-step launches + argmax/bookkeeping]; every per-step
@@ -1215,6 +1283,7 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
             if (rc || fin >= B) break;
         }
         for (auto& ln : s->lanes) {
+            if (trace_events_on() && it % 10 == 9) trace_mark(ln.st, "state %p lane %d step %d", (void*)s, ln.b0, it);
             if (ln.graph[0] && !no_graph) {
                 hipError_t e = hipGraphLaunch(ln.graph[it % wm_state::Lane::NEXEC], ln.st);
                 if (e != hipSuccess) {
@@ -1237,7 +1306,10 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
                 s->lanes.size(), std::chrono::duration<double>(t1 - t_loop0).count() * 1e6 / std::max(1, o->max_loop),
                 std::chrono::duration<double>(t2 - t1).count() * 1e3);
     }
-    for (auto& ln : s->lanes) HIPCHK(hipEventRecord(ln.done, ln.st));
+    for (auto& ln : s->lanes) {
+        trace_mark(ln.st, "state %p lane %d decode end", (void*)s, ln.b0);
+        HIPCHK(hipEventRecord(ln.done, ln.st));
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1266,6 +1338,7 @@ static int submit_on(wm_model* m, wm_state** slot, const float* mel, int mel_on_
     }
     wm_state* s = *slot;
     if (s->pending) return fail(WM_E_STATE, "this slot still holds a pass that was not waited for");
+    s->trace_id = slot == &m->cached ? 1 : 2 + (int)(slot - m->slots);
     // stream of this pass's encoder: the model stream (shared by all slots), or — WM_ENC_ON_LANE — the slot's own decode stream
     static const bool enc_on_lane = getenv("WM_ENC_ON_LANE") != nullptr;
     hipStream_t est = enc_on_lane ? s->lanes[0].st : m->stream;
@@ -1281,7 +1354,9 @@ static int submit_on(wm_model* m, wm_state** slot, const float* mel, int mel_on_
         mel_dev = s->mel_dev.as<float>();
     }
     const auto tt0 = std::chrono::steady_clock::now();
+    trace_mark(est, "state %p encoder start", (void*)s);
     WMCHK(run_encoder(m, s, mel_dev, B, est));
+    trace_mark(est, "state %p encoder end", (void*)s);
     s->enc_stream = est;
     s->has_enc = s->has_cross = true;
     s->last_mel = mel_dev;

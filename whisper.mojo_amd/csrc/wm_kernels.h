@@ -62,6 +62,8 @@ struct DecLinearParams {
     int* amax_idx;
     int amax_stride;
     const float* amax_mask;  // [N] additive mask (0 / -inf) applied to the argmax candidates only, or null
+    long long* ts;  // developer timeline (dec_logits only)
+    int ts_id;
 };
 template <typename TW> void launch_dec_linear(const DecLinearParams& p, hipStream_t st);
 template <typename TW> void launch_dec_logits(const DecLinearParams& p, hipStream_t st);
@@ -80,10 +82,12 @@ struct AttnDecParams {
     float* direct_out;  // non-null (nsplit must be 1): write the normalised output [B][d] here, skip the partials
     int H, d, B;
     int rps;  // filled by the launcher
+    long long* ts;  // developer timeline (null = off): see ts_put in kernels_decoder.hip
+    int ts_id;
 };
 template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStream_t st);
 void launch_attn_combine(const float* part_o, const float* part_ml, float* out, int B, int nsplit, int H, int d,
-                         hipStream_t st);
+                         hipStream_t st, long long* ts = nullptr, int ts_id = 0);
 
 void launch_dec_embed(const float* tok_emb, const float* pos_emb, const int* tok, const int* pos, float* x, int B, int d,
                       hipStream_t st);
@@ -103,6 +107,8 @@ struct ArgmaxParams {
     int eot, ignore_eot;
     int advance;  // != 0: also do the end-of-step bookkeeping (len += 1, pos[b] += 1)
     int* pos;
+    long long* ts;  // developer timeline (null = off)
+    int ts_id;
 };
 void launch_argmax_step(const ArgmaxParams& p, hipStream_t st);
 struct InitTokensParams {
