@@ -21,6 +21,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The pipelined passes decode on one HIP stream each; ROCm multiplexes streams onto GPU_MAX_HW_QUEUES (default 4)
+# hardware queues, and two passes that share a queue run one after the other.  Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 WORKLOADS = {
     #  name             (config, B/GPU, compute, kv)
@@ -94,7 +97,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after another")
-    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2, 3, 4], help="steps in flight (library pipeline slots)")
+    ap.add_argument("--pipeline", type=int, default=4, choices=[1, 2, 3, 4, 5, 6, 7, 8], help="steps in flight (library pipeline slots)")
     args = ap.parse_args()
 
     import torch
@@ -166,7 +169,14 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
-    log("model loaded, mels resident; warm-up")
+    log("model loaded, mels resident; set-up of the pipeline slots")
+    if not args.no_pipeline:  # allocate every slot's state and capture its step graph (set-up, not a step)
+        for sl in range(args.pipeline):
+            model.transcribe_submit(mel_dev, slot=sl, max_loop=2, ignore_eot=True)
+        for sl in range(args.pipeline):
+            model.transcribe_wait(sl)
+    sync()
+    log("warm-up")
     out = run_steps(args.warmup)
     sync()
     log("timed region")

@@ -170,9 +170,9 @@ struct wm_model {
         int chunk = 16;  // utterances per DFT GEMM
         DevBuf window, dft, fb, band, pcm, lens, frames, spec, logtmp, mel;
     } fe;
-    static const int NSLOT = 4;
+    static const int NSLOT = 8;
     wm_state* cached = nullptr;           // slot 0: the state behind wm_transcribe / wm_transcribe_submit(slot 0)
-    wm_state* slots[3] = {nullptr, nullptr, nullptr};  // slots 1..3: further pipeline stages (wm_transcribe_submit)
+    wm_state* slots[NSLOT - 1] = {};  // slots 1..7: further pipeline stages (wm_transcribe_submit)
 };
 
 struct wm_state {
@@ -1397,7 +1397,7 @@ extern "C" int wm_transcribe(wm_model* m, const float* mel, int mel_on_device, i
 // loop (the slot's decode stream) and returns; wait blocks until that slot's tokens are ready.  With two slots the
 // MFMA-bound encoder of batch i+1 overlaps the latency/HBM-bound decode of batch i.
 extern "C" int wm_transcribe_submit(wm_model* m, int slot, const float* mel, int mel_on_device, int B, const wm_decode_opts* o) {
-    if (!m || !mel || slot < 0 || slot >= wm_model::NSLOT) return fail(WM_E_ARG, "bad argument (slot must be 0..3)");
+    if (!m || !mel || slot < 0 || slot >= wm_model::NSLOT) return fail(WM_E_ARG, "bad argument (slot must be 0..7)");
     WMCHK(check_opts(m, o, B));
     return submit_on(m, slot == 0 ? &m->cached : &m->slots[slot - 1], mel, mel_on_device, B, o, false);
 }
