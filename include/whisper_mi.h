@@ -110,8 +110,10 @@ int wm_transcribe(wm_model* m, const float* mel, int mel_on_device, int B, const
 
 /* Pipelined form for back-to-back batches (serving / bench): wm_transcribe_submit enqueues the encoder (model stream) and
  * the whole greedy loop (the slot's decode stream) and returns immediately; wm_transcribe_wait blocks until that slot's
- * ids are ready and copies them out (same layout as wm_transcribe).  Four slots (0..3): submitting batch i+1 before
- * waiting for batch i overlaps its MFMA-bound encoder with batch i's latency/HBM-bound decode.  In this form every
+ * ids are ready and copies them out (same layout as wm_transcribe).  Eight slots (0..7): submitting batch i+1 before
+ * waiting for batch i overlaps its MFMA-bound encoder with batch i's latency/HBM-bound decode; four passes in flight is
+ * the measured optimum (the chip runs four hardware queues at a time, and ROCm must be allowed that many per-process
+ * queues: GPU_MAX_HW_QUEUES >= 8 in the environment before HIP initialises — see INTEGRATION.md).  In this form every
  * max_loop step is enqueued (no early exit); finished utterances simply stop recording, so the ids are identical to
  * wm_transcribe's.  mel must stay valid until the matching wait when it is a device pointer. */
 int wm_transcribe_submit(wm_model* m, int slot, const float* mel, int mel_on_device, int B, const wm_decode_opts* opts);
