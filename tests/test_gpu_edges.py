@@ -139,3 +139,20 @@ def test_pipelined_submit_wait_equals_synchronous(hip, micro_cfg, micro_weights)
         _lib.check(_lib.lib().wm_transcribe_wait(m._h, 0, None, None) if False else _lib.lib().wm_transcribe_wait(
             m._h, 0, np.zeros(4, np.int32).ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_int32)),
             np.zeros(4, np.int32).ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_int32))))
+
+
+def test_eight_slots_in_flight(hip, micro_cfg, micro_weights):
+    """All eight pipeline slots in flight at once, different batches and batch sizes per slot, waited out of order:
+    every slot returns exactly the synchronous call's ids; slot 8 does not exist."""
+    from whisper_mojo_amd import _lib, synth
+    m = make_model(micro_cfg, micro_weights, max_batch=4)
+    kw = dict(prompt=(1, 2, 3, 4), eot=-1, max_loop=10)
+    mels = [synth.synth_mels(micro_cfg, 100 + 7 * s, 1 + s % 4) for s in range(8)]
+    want = [m.transcribe_batch(x, **kw) for x in mels]
+    for rnd in range(2):  # second round reuses every slot's state and graph
+        for s in range(8):
+            m.transcribe_submit(mels[s], slot=s, **kw)
+        for s in (3, 0, 7, 1, 6, 2, 5, 4):
+            assert m.transcribe_wait(s) == want[s], (rnd, s)
+    with pytest.raises(_lib.WhisperMiError, match="slot"):
+        m.transcribe_submit(mels[0], slot=8, **kw)
