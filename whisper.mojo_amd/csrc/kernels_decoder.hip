@@ -53,8 +53,11 @@ void launch_dec_embed(const float* tok_emb, const float* pos_emb, const int* tok
 //     requested before anything else so they ride the same round trip.
 template <typename TW, int KPW, bool LN, int NT>
 __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
-    __shared__ float s_stat[16][16][2];
-    __shared__ __attribute__((aligned(16))) f32x4 s_red[16][NT][64];
+    // dynamic LDS, sized by the launcher for the NW waves actually used: [NW][NT][64] f32x4 K-partials, then [NW][16][2]
+    // LayerNorm statistics (24.6 + 1.5 KB for the 12-wave QKV / fc1 launches: fits beside two 64-KB GEMM workgroups)
+    extern __shared__ __attribute__((aligned(16))) unsigned char dl_smem[];
+    f32x4 (*s_red)[NT][64] = reinterpret_cast<f32x4 (*)[NT][64]>(dl_smem);
+    float (*s_stat)[16][2] = reinterpret_cast<float (*)[16][2]>(dl_smem + (size_t)(blockDim.x >> 6) * NT * 64 * sizeof(f32x4));
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * (16 * NT), b0 = blockIdx.y * 16;
@@ -190,16 +193,17 @@ template <typename TW, int KPW> static void launch_dec_linear_t(const DecLinearP
     // fragment (and one LayerNorm) feeding two MFMAs
     const bool wide = p.N >= 1024 && nw >= 2;
     const dim3 grid((p.N + (wide ? 31 : 15)) / (wide ? 32 : 16), (p.B + 15) / 16), block(nw * 64);
+    auto smem = [&](int nt) { return (size_t)nw * nt * 64 * sizeof(f32x4) + (size_t)nw * 16 * 2 * sizeof(float); };
     if (p.ln_g) {
         if (wide)
-            hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, true, 2>), grid, block, 0, st, p);
+            hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, true, 2>), grid, block, smem(2), st, p);
         else
-            hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, true, 1>), grid, block, 0, st, p);
+            hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, true, 1>), grid, block, smem(1), st, p);
     } else {
         if (wide)
-            hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, false, 2>), grid, block, 0, st, p);
+            hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, false, 2>), grid, block, smem(2), st, p);
         else
-            hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, false, 1>), grid, block, 0, st, p);
+            hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, false, 1>), grid, block, smem(1), st, p);
     }
 }
 // K % 32 == 0 and (K/32) must factor as NW * KPW with NW <= 16, KPW <= 4 (true for every K = 128·j, j <= 16).

@@ -68,52 +68,58 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + j * 16 + g * 4);
     }
-    bool valid[4];
+    // two halves of 32 rows: 8 addend fragments in flight per half keeps the kernel near 200 VGPRs, which leaves room on
+    // a SIMD for a latency-bound wave of another queue (a decode step beside the encoder)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) valid[i] = m0 + i * 16 + r16 < p.M;
-    f32x4 ex[4][4];  // post-activation addend: pos + residual
+    for (int hf = 0; hf < 2; ++hf) {
+        bool valid[2];
+        f32x4 ex[2][4];  // post-activation addend: pos + residual
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int ii = 0; ii < 2; ++ii) {
+            valid[ii] = m0 + (hf * 2 + ii) * 16 + r16 < p.M;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ex[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.residual) {
-        const float* Rb = p.residual + (size_t)bz * p.strideR + n0 + g * 4;
+            for (int j = 0; j < 4; ++j) ex[ii][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (p.residual) {
+            const float* Rb = p.residual + (size_t)bz * p.strideR + n0 + g * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (valid[i]) {
-                const float* rr = Rb + (size_t)(m0 + i * 16 + r16) * p.ldr;
+            for (int ii = 0; ii < 2; ++ii)
+                if (valid[ii]) {
+                    const float* rr = Rb + (size_t)(m0 + (hf * 2 + ii) * 16 + r16) * p.ldr;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ex[i][j] = *reinterpret_cast<const f32x4*>(rr + j * 16);
-            }
-    }
-    if (p.pos) {
-        const float* Pb = p.pos + n0 + g * 4;
+                    for (int j = 0; j < 4; ++j) ex[ii][j] = *reinterpret_cast<const f32x4*>(rr + j * 16);
+                }
+        }
+        if (p.pos) {
+            const float* Pb = p.pos + n0 + g * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (valid[i]) {
-                const float* pr = Pb + (size_t)(m0 + i * 16 + r16) * p.N;
+            for (int ii = 0; ii < 2; ++ii)
+                if (valid[ii]) {
+                    const float* pr = Pb + (size_t)(m0 + (hf * 2 + ii) * 16 + r16) * p.N;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ex[i][j] += *reinterpret_cast<const f32x4*>(pr + j * 16);
-            }
-    }
+                    for (int j = 0; j < 4; ++j) ex[ii][j] += *reinterpret_cast<const f32x4*>(pr + j * 16);
+                }
+        }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (!valid[i]) continue;
-        TO* crow = Cb + (size_t)(m0 + i * 16 + r16) * p.ldc + nc;
+        for (int ii = 0; ii < 2; ++ii) {
+            if (!valid[ii]) continue;
+            const int i = hf * 2 + ii;
+            TO* crow = Cb + (size_t)(m0 + i * 16 + r16) * p.ldc + nc;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 v = acc[j][i] + bv[j];
-            if (p.act) {
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = acc[j][i] + bv[j];
+                if (p.act) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = FASTG ? gelu_fast(v[r], p.gelu_mode) : gelu_f(v[r], p.gelu_mode);
-            }
-            v += ex[i][j];
-            if constexpr (sizeof(TO) == 4) {
-                *reinterpret_cast<f32x4*>((float*)crow + j * 16) = v;
-            } else {
-                typedef __attribute__((ext_vector_type(4))) TO to4;
-                to4 o = {from_f32<TO>(v[0]), from_f32<TO>(v[1]), from_f32<TO>(v[2]), from_f32<TO>(v[3])};
-                *reinterpret_cast<to4*>(crow + j * 16) = o;
+                    for (int r = 0; r < 4; ++r) v[r] = FASTG ? gelu_fast(v[r], p.gelu_mode) : gelu_f(v[r], p.gelu_mode);
+                }
+                v += ex[ii][j];
+                if constexpr (sizeof(TO) == 4) {
+                    *reinterpret_cast<f32x4*>((float*)crow + j * 16) = v;
+                } else {
+                    typedef __attribute__((ext_vector_type(4))) TO to4;
+                    to4 o = {from_f32<TO>(v[0]), from_f32<TO>(v[1]), from_f32<TO>(v[2]), from_f32<TO>(v[3])};
+                    *reinterpret_cast<to4*>(crow + j * 16) = o;
+                }
             }
         }
     }
