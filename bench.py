@@ -91,8 +91,8 @@ def log(msg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=12)  # a multiple of the pipeline depth: passes complete in groups of four
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="tiny_b64_bf16", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")

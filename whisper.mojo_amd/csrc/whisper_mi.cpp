@@ -652,11 +652,12 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
     s->Bc = std::min(B, m->enc_chunk);
     // key chunks per utterance for the cross-attention kernel: a function of the MODEL's max_batch, never of this call's
     // B, so that an utterance's result does not depend on how it was batched (bitwise batch invariance within a model).
-    // Aim for >= 768 workgroups at full batch: 12 chunks at max_batch 64, up to 48 for small-batch / latency models
-    // (B = 1: 12.1 -> 4 us per launch).  WM_NSPLIT overrides for tuning.
+    // Aim for 1024 workgroups at full batch (4 per CU, one full round): 16 chunks at max_batch 64 (measured, µs per launch /
+    // per whole step: 12 chunks 26.4 / 280, 16: 25.2 / 273, 20: 25.5 / 278, 24: 26.4 / 278), up to 48 for small-batch /
+    // latency models (B = 1: 12.1 -> 4 us per launch).  WM_NSPLIT overrides for tuning.
     {
         const int min_split = (int)((T + 511) / 512);
-        int ns = (768 + m->cfg.max_batch - 1) / m->cfg.max_batch;
+        int ns = (1024 + m->cfg.max_batch - 1) / m->cfg.max_batch;
         ns = std::max(12, std::min(48, ns));
         ns = std::max(min_split, std::min(ns, (int)((T + 31) / 32)));
         if (const char* e = getenv("WM_NSPLIT")) ns = std::max(min_split, std::min(64, atoi(e)));
@@ -1339,8 +1340,11 @@ static int submit_on(wm_model* m, wm_state** slot, const float* mel, int mel_on_
     wm_state* s = *slot;
     if (s->pending) return fail(WM_E_STATE, "this slot still holds a pass that was not waited for");
     s->trace_id = slot == &m->cached ? 1 : 2 + (int)(slot - m->slots);
-    // stream of this pass's encoder: the model stream (shared by all slots), or — WM_ENC_ON_LANE — the slot's own decode stream
-    static const bool enc_on_lane = getenv("WM_ENC_ON_LANE") != nullptr;
+    // The whole pass — encoder, prefill, greedy loop — goes on the slot's own stream: four slots are then four hardware
+    // queues, which is what the chip runs concurrently (a fifth queue, e.g. a shared encoder stream, lands on a pipe that
+    // already serves one of them and the two take turns: 22.3 vs 20.8 ms per pass at four passes in flight).
+    // WM_ENC_ON_MODEL_STREAM=1 restores the shared encoder stream for A/B runs.
+    static const bool enc_on_lane = getenv("WM_ENC_ON_MODEL_STREAM") == nullptr;
     hipStream_t est = enc_on_lane ? s->lanes[0].st : m->stream;
     s->has_enc = s->has_cross = false;
     s->host_len = 0;
