@@ -234,7 +234,11 @@ template void launch_dec_linear<f16>(const DecLinearParams&, hipStream_t);
 // operands, so L2 sees x once per 128 columns; each wave then streams its 32 embedding rows straight from HBM into
 // registers (all k-steps in flight) and needs no cross-wave reduction.
 template <typename TW, int KD /* d_model/128 */, int NRB>
-__global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
+__global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int CT) {
+    // One workgroup = 8 waves = CT <= 16 column tiles of 16 vocabulary rows (wave w owns tiles w and w+8), all NRB*16
+    // utterance rows.  CT is chosen by the launcher so that the whole vocabulary is ONE round of <= 256 workgroups
+    // (51 865 rows: CT = 13 -> 250 workgroups, 160 KB of embedding rows per CU): the kernel is a single pass over the
+    // embedding at one workgroup per CU instead of 406 128-column workgroups in two rounds (16.5 -> ~10 us).
     constexpr int K = KD * 128;
     constexpr int PAD = 16 / sizeof(TW);
     constexpr int PITCH = K + PAD;
@@ -242,36 +246,40 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
     constexpr int CHK = sizeof(TW) == 2 ? KS : KS / 2;  // k-steps whose weight fragments are in flight together
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     TW* xs = reinterpret_cast<TW*>(smem_raw);  // [NRB*16][PITCH]
-    __shared__ float s_av[4][NRB * 16];
-    __shared__ int s_ai[4][NRB * 16];
+    __shared__ float s_av[8][NRB * 16];
+    __shared__ int s_ai[8][NRB * 16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int row0 = blockIdx.y * NRB * 16;
     if (p.ts && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ts_put(p.ts, p.ts_id, 2);
     const int nrows = min(NRB * 16, p.B - row0);
-    const int n0 = blockIdx.x * 128 + w * 32;
+    int n0[2];
+    bool have[2];
     const TW* wp[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-        int wr = n0 + nb * 16 + r16;
+        const int t = w + 8 * nb;  // column tile inside this workgroup
+        n0[nb] = (blockIdx.x * CT + t) * 16;
+        have[nb] = t < CT && n0[nb] < p.N;  // wave-uniform
+        int wr = n0[nb] + r16;
         wr = wr < p.N ? wr : p.N - 1;
         wp[nb] = (const TW*)p.W + (size_t)wr * K + g * 8;
     }
     // Memory operations retire in issue order (vmcnt), so the activation rows are requested FIRST and the embedding
     // rows right behind them: the LayerNorm staging below waits only for the (L2-resident) activations and runs while
-    // this wave's 24 KB of embedding rows are still streaming from HBM.
+    // this wave's embedding rows are still streaming from HBM.
     Frag<TW> wf[2][CHK];
     __shared__ __attribute__((aligned(16))) float s_gb[2][K];  // LN gamma / beta, fetched ahead of the embedding rows too
-    {  // LN + convert -> LDS.  thread t: row t>>2 (+64 per pass), quarter t&3 of the row, float4 index q + 4*i
+    {  // LN + convert -> LDS.  thread t: row t>>3 (+64 per pass), eighth t&7 of the row, float4 index q + 8*i
         for (int rbase = 0; rbase < NRB * 16; rbase += 64) {
-            const int lr = rbase + (threadIdx.x >> 2), q = threadIdx.x & 3;
-            f32x4 v[KD * 8];
+            const int lr = rbase + (threadIdx.x >> 3), q = threadIdx.x & 7;
+            f32x4 v[KD * 4];
             const bool mine = lr < NRB * 16;
             if (mine) {
                 const int row = min(lr, nrows - 1);
                 const float* xr = p.x + (size_t)(row0 + row) * p.ldx;
 #pragma unroll
-                for (int i = 0; i < KD * 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * (q + 4 * i));
+                for (int i = 0; i < KD * 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * (q + 8 * i));
             }
             if (rbase == 0) {
                 f32x4 gbv = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -279,30 +287,33 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
                 if (gi < K / 2) gbv = *reinterpret_cast<const f32x4*>((gi < K / 4 ? p.ln_g : p.ln_b - K) + 4 * gi);
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
+                    if (have[nb]) {
 #pragma unroll
-                    for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + i * 32);
+                        for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + i * 32);
+                    }
                 if (gi < K / 2) *reinterpret_cast<f32x4*>(&s_gb[0][0] + 4 * gi) = gbv;
                 __syncthreads();
             }
             if (mine) {
                 float sm = 0.f, sq = 0.f;
 #pragma unroll
-                for (int i = 0; i < KD * 8; ++i)
+                for (int i = 0; i < KD * 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         sm += v[i][j];
                         sq += v[i][j] * v[i][j];
                     }
-                sm += __shfl_xor(sm, 1, 64);
-                sq += __shfl_xor(sq, 1, 64);
-                sm += __shfl_xor(sm, 2, 64);
-                sq += __shfl_xor(sq, 2, 64);
+#pragma unroll
+                for (int o = 1; o <= 4; o <<= 1) {
+                    sm += __shfl_xor(sm, o, 64);
+                    sq += __shfl_xor(sq, o, 64);
+                }
                 const float mean = sm / (float)K;
                 const float var = (sq / (float)K) - (mean * mean);
                 const float rstd = 1.0f / sqrtf(var + 1e-5f);
 #pragma unroll
-                for (int i = 0; i < KD * 8; ++i) {
-                    const int k = 4 * (q + 4 * i);
+                for (int i = 0; i < KD * 4; ++i) {
+                    const int k = 4 * (q + 8 * i);
                     const f32x4 gm = *reinterpret_cast<const f32x4*>(&s_gb[0][k]), bt = *reinterpret_cast<const f32x4*>(&s_gb[1][k]);
                     typedef __attribute__((ext_vector_type(4))) TW t4;
                     t4 o;
@@ -325,8 +336,10 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
         if (c > 0) {
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
+                if (have[nb]) {
 #pragma unroll
-                for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + (c * CHK + i) * 32);
+                    for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + (c * CHK + i) * 32);
+                }
         }
 #pragma unroll
         for (int i = 0; i < CHK; ++i) {
@@ -334,11 +347,12 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
             for (int rb = 0; rb < NRB; ++rb) {
                 Frag<TW> xf = load_frag<TW>(&xs[(rb * 16 + r16) * PITCH + (c * CHK + i) * 32 + g * 8]);
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) acc[nb][rb] = mma32(wf[nb][i], xf, acc[nb][rb]);
+                for (int nb = 0; nb < 2; ++nb)
+                    if (have[nb]) acc[nb][rb] = mma32(wf[nb][i], xf, acc[nb][rb]);
             }
         }
     }
-    // acc[nb][rb][r] = logits[row0 + 16 rb + r16][n0 + 16 nb + 4 g + r]
+    // acc[nb][rb][r] = logits[row0 + 16 rb + r16][n0[nb] + 4 g + r]
     if (p.out) {
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
@@ -346,14 +360,14 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
             if (lr < nrows) {
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
-                    const int n = n0 + nb * 16 + g * 4;
-                    if (n < p.ldo) *reinterpret_cast<f32x4*>(p.out + (size_t)(row0 + lr) * p.ldo + n) = acc[nb][rb];
+                    const int n = n0[nb] + g * 4;
+                    if (have[nb] && n < p.ldo) *reinterpret_cast<f32x4*>(p.out + (size_t)(row0 + lr) * p.ldo + n) = acc[nb][rb];
                 }
             }
         }
     }
     if (p.amax_val) {
-        // fused argmax, stage 1 (whisper_tensor.mojo:431-439: lowest index wins): this workgroup's best of its 128
+        // fused argmax, stage 1 (whisper_tensor.mojo:431-439: lowest index wins): this workgroup's best of its CT*16
         // columns per utterance.  Lane-local over 8 columns, 2 butterfly steps over the 4 lanes of a row, LDS over waves.
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
@@ -363,9 +377,9 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int n = n0 + nb * 16 + g * 4 + r;
+                    const int n = n0[nb] + g * 4 + r;
                     const float v = acc[nb][rb][r] + (p.amax_mask ? p.amax_mask[min(n, p.N - 1)] : 0.f);  // 0 or -inf
-                    if (n < p.N && v > bv) {  // n increases through the loop: strict '>' keeps the lowest index
+                    if (have[nb] && n < p.N && v > bv) {  // n increases through the loop: strict '>' keeps the lowest index
                         bv = v;
                         bi = n;
                     }
@@ -389,7 +403,7 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
             float bv = s_av[0][threadIdx.x];
             int bi = s_ai[0][threadIdx.x];
 #pragma unroll
-            for (int k = 1; k < 4; ++k) {
+            for (int k = 1; k < 8; ++k) {
                 const float v2 = s_av[k][threadIdx.x];
                 const int i2 = s_ai[k][threadIdx.x];
                 if (v2 > bv || (v2 == bv && i2 < bi)) {
@@ -403,18 +417,28 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(DecLinearParams p) {
         }
     }
 }
+// column tiles (of 16) per workgroup: the smallest count that covers the vocabulary with <= 256 workgroups, at most 16
+int dec_logits_tiles_per_wg(int N) {
+    const int tiles = (N + 15) / 16;
+    return std::max(1, std::min(16, (tiles + 255) / 256));
+}
+int dec_logits_parts(int N) {
+    const int tiles = (N + 15) / 16, ct = dec_logits_tiles_per_wg(N);
+    return (tiles + ct - 1) / ct;
+}
 template <typename TW, int KD, int NRB> static void launch_dec_logits_t(const DecLinearParams& p, hipStream_t st) {
     const size_t lds = (size_t)NRB * 16 * (KD * 128 + 16 / sizeof(TW)) * sizeof(TW);
     static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
+    if (!attr_set && lds > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_logits_kernel<TW, KD, NRB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 grid((p.N + 127) / 128, (p.B + NRB * 16 - 1) / (NRB * 16));
-    hipLaunchKernelGGL((dec_logits_kernel<TW, KD, NRB>), grid, dim3(256), lds, st, p);
+    const int ct = dec_logits_tiles_per_wg(p.N);
+    dim3 grid(dec_logits_parts(p.N), (p.B + NRB * 16 - 1) / (NRB * 16));
+    hipLaunchKernelGGL((dec_logits_kernel<TW, KD, NRB>), grid, dim3(512), lds, st, p, ct);
 }
-// requires ln_g/ln_b, no bias/act/residual, K in {128, 384, 512}, ldo % 4 == 0
+// requires ln_g/ln_b, no bias/act/residual, K in {128, 384, 512}, ldo % 4 == 0; amax_stride >= dec_logits_parts(N)
 template <typename TW> void launch_dec_logits(const DecLinearParams& p, hipStream_t st) {
     const int kd = p.K >> 7;
     if (p.B <= 16) {
@@ -572,6 +596,8 @@ template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStrea
     // fp32 K/V rows are twice as wide (96-128 lanes per row): the latency-bound self-attention takes 512 threads so a
     // lane's serial key loop stays short (61 keys: 16 -> 7 iterations)
     q.rps = ((sizeof(TKV) == 4 && p.n_keys < 0) ? 512 : 256) / LPR;
+    static const int thr_cross = getenv("WM_ATTN_THREADS") ? atoi(getenv("WM_ATTN_THREADS")) : 0;  // A/B: cross-attention block size
+    if (thr_cross && p.n_keys >= 0) q.rps = std::max(1, std::min(512, thr_cross) / LPR);
     // block rounded up to whole waves: the spare lanes take no rows (rslot >= RPS) but stay in the DPP groups
     const dim3 grid(p.nsplit, p.B), block((q.rps * LPR + 63) / 64 * 64);
     static const bool nt_off = getenv("WM_NO_NT") != nullptr;

@@ -213,7 +213,7 @@ struct wm_state {
     std::vector<int32_t> sup_cached, bsup_cached;
     bool masks_valid = false;
     DevBuf dx, dq, dattn, dhid, part_o, part_ml, logits, amax_val, amax_idx, tok, pos, ctl, out_tokens, n_tokens, finished;
-    int npart = 0;  // fused-argmax partials per utterance = ceil(vocab / 128)
+    int npart = 0;  // fused-argmax partials per utterance = workgroups per row block of the logits kernel
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -689,7 +689,7 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
     A(s->part_o, (size_t)B * s->nsplit * d * 4);
     A(s->part_ml, (size_t)B * s->nsplit * c.n_heads * 2 * 4);
     A(s->logits, (size_t)B * m->Vpad * 4);
-    s->npart = (c.vocab + 127) / 128;
+    s->npart = dec_logits_parts(c.vocab);
     A(s->amax_val, (size_t)B * s->npart * 4);
     A(s->amax_idx, (size_t)B * s->npart * 4);
     A(s->mask_steady, (size_t)m->Vpad * 4, true);

@@ -67,6 +67,7 @@ struct DecLinearParams {
 };
 template <typename TW> void launch_dec_linear(const DecLinearParams& p, hipStream_t st);
 template <typename TW> void launch_dec_logits(const DecLinearParams& p, hipStream_t st);
+int dec_logits_parts(int N);  // fused-argmax partials per utterance that launch_dec_logits writes (amax_stride must cover them)
 
 struct AttnDecParams {
     const float* q;  // [B][d] fp32
