@@ -8,6 +8,7 @@
 #include "wm_kernels.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace wm {
 
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
     for (int nb = 0; nb < 2; ++nb) {
         const int t = w + 8 * nb;  // column tile inside this workgroup
         n0[nb] = (blockIdx.x * CT + t) * 16;
-        have[nb] = t < CT && n0[nb] < p.N;  // wave-uniform
+        have[nb] = __builtin_amdgcn_readfirstlane((int)(t < CT && n0[nb] < p.N)) != 0;  // wave-uniform, and the compiler knows
         int wr = n0[nb] + r16;
         wr = wr < p.N ? wr : p.N - 1;
         wp[nb] = (const TW*)p.W + (size_t)wr * K + g * 8;
@@ -331,27 +332,33 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) acc[nb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // straight-line MFMA bodies for "both tiles" / "first tile only" (have[1] implies have[0]); a per-MFMA predicate
+    // would put a branch and a wait around every instruction
+    auto body = [&](auto NB) {
+        constexpr int nbn = decltype(NB)::value;
 #pragma unroll
-    for (int c = 0; c < KS / CHK; ++c) {
-        if (c > 0) {
+        for (int c = 0; c < KS / CHK; ++c) {
+            if (c > 0) {
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-                if (have[nb]) {
+                for (int nb = 0; nb < nbn; ++nb)
 #pragma unroll
                     for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + (c * CHK + i) * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < CHK; ++i) {
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    Frag<TW> xf = load_frag<TW>(&xs[(rb * 16 + r16) * PITCH + (c * CHK + i) * 32 + g * 8]);
+#pragma unroll
+                    for (int nb = 0; nb < nbn; ++nb) acc[nb][rb] = mma32(wf[nb][i], xf, acc[nb][rb]);
                 }
-        }
-#pragma unroll
-        for (int i = 0; i < CHK; ++i) {
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) {
-                Frag<TW> xf = load_frag<TW>(&xs[(rb * 16 + r16) * PITCH + (c * CHK + i) * 32 + g * 8]);
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-                    if (have[nb]) acc[nb][rb] = mma32(wf[nb][i], xf, acc[nb][rb]);
             }
         }
-    }
+    };
+    if (have[1])
+        body(std::integral_constant<int, 2>{});
+    else if (have[0])
+        body(std::integral_constant<int, 1>{});
     // acc[nb][rb][r] = logits[row0 + 16 rb + r16][n0[nb] + 4 g + r]
     if (p.out) {
 #pragma unroll
