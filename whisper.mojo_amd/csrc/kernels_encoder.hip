@@ -6,6 +6,7 @@
 // layers.mojo:273-342, layer_norm whisper_tensor.mojo:249-285, residual adds layers.mojo:457-461,483-487,513-517.
 #include "wm_kernels.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace wm {
@@ -251,10 +252,209 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmParams p) {
     gemm_epilogue<TO, true>(p, acc, bm + wm * 64, bn + wn * 64, bz, r16, g);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Row-panel GEMM for K <= 512 (QKV, fc1, cross-K/V: K = d_model): the A operand is STATIONARY IN REGISTERS.
+// The 128x128-tile kernel above stages 192 KB per K = 384 tile, half of it the activation panel that comes from HBM / the
+// Infinity Cache, and is bound by that staging (8 TB/s aggregate at 540 TFLOP/s).  Here a wave owns 32 rows of a 128-row
+// panel and keeps their whole K extent as MFMA fragments (2 x K/32 fragments = 96 VGPRs at K = 384), loaded once per panel;
+// only W tiles stream through LDS — L2-resident (<= 2.4 MB), 96 KB per 128x128 output tile — in 16 KB stages of 64 k
+// through a 4-slot ring filled by global_load_lds three stages ahead, across column tiles and panels (counted vmcnt, raw
+// s_barrier: the ring never drains).  A workgroup walks a contiguous range of (panel, column tile) units, column tile
+// fastest, so a panel's A fragments are fetched by one or two workgroups.  Bias is folded into the accumulator
+// initialisation from an LDS copy (no VMEM loads inside the stream).  No residual / positional addends (launcher).
+template <typename T, typename TO, int KS /* K / 32 */>
+__global__ __launch_bounds__(256, 2) void gemm_nt_rowpanel_kernel(GemmParams p, int n_units) {
+    constexpr int SPU = KS / 2;       // 64-k stages per unit
+    constexpr int NSLOT = 4;          // ring slots of 128 rows x 64 k
+    constexpr int SLOT = 128 * 64;    // elements per slot
+    extern __shared__ __attribute__((aligned(16))) unsigned char rp_smem[];  // ONE LDS object: ring, then fp32 bias [N]
+    T* ring = reinterpret_cast<T*>(rp_smem);
+    float* s_bias = reinterpret_cast<float*>(rp_smem + (size_t)NSLOT * SLOT * sizeof(T));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int nct = p.N >> 7;
+    const int u0 = (int)((long)blockIdx.x * n_units / gridDim.x), u1 = (int)((long)(blockIdx.x + 1) * n_units / gridDim.x);
+    const int n_stage = (u1 - u0) * SPU;
+    const T* Wg = (const T*)p.W;
+    for (int i = threadIdx.x; i < p.N; i += 256) s_bias[i] = p.bias ? p.bias[i] : 0.f;
+    __syncthreads();  // before any DMA is in flight: a __syncthreads() later would drain the ring (vmcnt(0))
+
+    auto issue = [&](int s) {  // stage s of this workgroup's stream -> ring slot s % 4
+        const int u = u0 + s / SPU, t = s % SPU;
+        const int ct = u % nct;
+        stage_tile<T>(Wg + (size_t)ct * 128 * p.ldw + t * 64, p.ldw, ring + (s & (NSLOT - 1)) * SLOT, lane, w);
+    };
+#pragma unroll
+    for (int s = 0; s < NSLOT - 1; ++s)
+        if (s < n_stage) issue(s);
+
+    Frag<T> a[2][KS];
+    f32x4 acc[8][2];
+    int panel = -1;
+    bool st_pend = false;  // the previous unit's 16 stores sit between the DMAs in this wave's VMEM queue
+#define WM_RP_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    for (int u = u0, s = 0; u < u1; ++u) {
+        const int pn = u / nct, ct = u % nct;
+        const bool newp = pn != panel;
+        if (newp) {  // new panel: this wave's 32 rows, whole K, straight to registers (rows past M clamp to the last)
+            panel = pn;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int row = pn * 128 + w * 32 + i * 16 + r16;
+                row = row < p.M ? row : p.M - 1;
+                const T* ar = (const T*)p.A + (size_t)row * p.lda + g * 8;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) a[i][k] = load_frag<T>(ar + k * 32);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(&s_bias[ct * 128 + j * 16 + g * 4]);
+            acc[j][0] = b4;
+            acc[j][1] = b4;
+        }
+#pragma unroll
+        for (int t = 0; t < SPU; ++t, ++s) {
+            // Stage s must have landed.  vmcnt(N) = all but the N youngest VMEM operations of this wave are done, and
+            // loads, stores and LDS-DMA count together in issue order: younger than stage s are the (<= 2) stages issued
+            // after it, 4 DMAs each, plus — for the first three stages after an epilogue — that epilogue's 8 or 16 stores.
+            // The barrier then also says everyone is done reading slot (s-1) % 4, which the next DMA overwrites.
+            const int rem = n_stage - 1 - s;
+            if (t == 0 && newp) {  // fresh A fragments: the compiler waits vmcnt(0) for them anyway
+                WM_RP_WAIT(0);
+            } else if (t < 3 && st_pend) {
+                if constexpr (sizeof(TO) == 2) {  // 8 epilogue stores
+                    if (rem >= 2)
+                        WM_RP_WAIT(16);
+                    else if (rem == 1)
+                        WM_RP_WAIT(12);
+                    else
+                        WM_RP_WAIT(8);
+                } else {  // 16 epilogue stores
+                    if (rem >= 2)
+                        WM_RP_WAIT(24);
+                    else if (rem == 1)
+                        WM_RP_WAIT(20);
+                    else
+                        WM_RP_WAIT(16);
+                }
+            } else {
+                if (rem >= 2)
+                    WM_RP_WAIT(8);
+                else if (rem == 1)
+                    WM_RP_WAIT(4);
+                else
+                    WM_RP_WAIT(0);
+            }
+            if (s + NSLOT - 1 < n_stage) issue(s + NSLOT - 1);
+            const T* Ws = ring + (s & (NSLOT - 1)) * SLOT;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                // all 8 W fragments of the k-step requested first (32 VGPRs), then the 16 MFMAs: left alone the compiler
+                // reuses one 8-register pair and exposes the LDS latency in front of every four MFMAs
+                Frag<T> bf[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int rb = j * 16 + r16;
+                    bf[j] = load_frag<T>(Ws + rb * 64 + (((ks * 4 + g) ^ (rb & 7)) << 3));
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // 8 DS reads
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc[j][0] = mma32(bf[j], a[0][t * 2 + ks], acc[j][0]);
+                    acc[j][1] = mma32(bf[j], a[1][t * 2 + ks], acc[j][1]);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // 16 MFMAs
+            }
+        }
+        // epilogue: acc[j][i][r] = C[pn*128 + w*32 + 16i + r16][ct*128 + 16j + 4g + r]
+        TO* Cb = (TO*)p.C;
+        int ncol = ct * 128;
+        if (p.group_n > 0) {
+            const int grp = ncol / p.group_n;
+            Cb += (size_t)grp * p.group_stride;
+            ncol -= grp * p.group_n;
+        }
+        if constexpr (sizeof(TO) == 2) {
+            // 16-bit output: a lane's 4 columns are 8 bytes, a wave store of them is 16 rows x 32 B — quarter lines, and
+            // the three wide GEMMs ran at the resulting ~1.3 TB/s of output.  Transpose through LDS instead: the ring slot
+            // just consumed is free until the next stage's DMA (issued after that stage's barrier); each wave takes 4 KB
+            // of it = 16 rows x 256 B, written as [row][16-byte chunk ^ row] and read back 4 whole rows per instruction.
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone is done reading this slot
+            unsigned char* scr = reinterpret_cast<unsigned char*>(ring + ((s - 1) & (NSLOT - 1)) * SLOT) + w * 4096;
+            typedef __attribute__((ext_vector_type(4))) TO to4;
+            typedef __attribute__((ext_vector_type(8))) TO to8;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    f32x4 v = acc[j][i];
+                    if (p.act) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r], p.gelu_mode);
+                    }
+                    const to4 o = {from_f32<TO>(v[0]), from_f32<TO>(v[1]), from_f32<TO>(v[2]), from_f32<TO>(v[3])};
+                    const int chunk = (2 * j + (g >> 1)) ^ r16;
+                    *reinterpret_cast<to4*>(scr + r16 * 256 + chunk * 16 + (g & 1) * 8) = o;
+                }
+                const int mbase = pn * 128 + w * 32 + i * 16;
+                if (mbase < p.M) {  // wave-uniform: 4 store instructions (rows past M masked per lane)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int row = 4 * k + (lane >> 4), cl = lane & 15;
+                        const to8 v8 = *reinterpret_cast<const to8*>(scr + row * 256 + ((cl ^ row) * 16));
+                        if (mbase + row < p.M) *reinterpret_cast<to8*>(Cb + (size_t)(mbase + row) * p.ldc + ncol + cl * 8) = v8;
+                    }
+                }
+            }
+            // exactly 8 store instructions per wave when all its 32 rows exist; otherwise (last panel) drain, don't count
+            st_pend = __builtin_amdgcn_readfirstlane((int)(pn * 128 + w * 32 + 32 <= p.M)) != 0;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = pn * 128 + w * 32 + i * 16 + r16;
+                if (m >= p.M) continue;
+                float* crow = (float*)Cb + (size_t)m * p.ldc + ncol + g * 4;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    f32x4 v = acc[j][i];
+                    if (p.act) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r], p.gelu_mode);
+                    }
+                    *reinterpret_cast<f32x4*>(crow + j * 16) = v;
+                }
+            }
+            // exactly 16 store instructions per wave when all its 32 rows exist
+            st_pend = __builtin_amdgcn_readfirstlane((int)(pn * 128 + w * 32 + 32 <= p.M)) != 0;
+        }
+        if (!st_pend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#undef WM_RP_WAIT
+}
+template <typename T, typename TO, int KS> static void launch_rowpanel(const GemmParams& p, hipStream_t st) {
+    const int n_units = ((p.M + 127) / 128) * (p.N / 128);
+    static const int grid_max = getenv("WM_RP_GRID") ? atoi(getenv("WM_RP_GRID")) : 512;  // two 64-KB-ring workgroups per CU
+    const int grid = std::min(n_units, grid_max);
+    const size_t lds = (size_t)4 * 128 * 64 * sizeof(T) + (size_t)p.N * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_rowpanel_kernel<T, TO, KS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_rowpanel_kernel<T, TO, KS>), dim3(grid), dim3(256), lds, st, p, n_units);
+}
+
 template <typename T, typename TO> void launch_gemm_nt(const GemmParams& p, int batch, hipStream_t st) {
     dim3 grid(p.N / 128, (p.M + 127) / 128, batch);
     static const bool no_lds = getenv("WM_GEMM_DIRECT") != nullptr;
     if constexpr (sizeof(T) == 2) {
+        // A-stationary row-panel kernel: plain [M,K]x[N,K] (no conv batching), K = 384 (K = 512 needs 128 A registers: spills), no addends, N <= 3072
+        static const bool no_rp = getenv("WM_GEMM_NO_ROWPANEL") != nullptr;
+        if (!no_rp && !no_lds && batch == 1 && !p.residual && !p.pos && p.N <= 3072 && (p.group_n == 0 || p.group_n % 128 == 0)) {
+            if (p.K == 384) return launch_rowpanel<T, TO, 12>(p, st);
+        }
         if (!no_lds && (p.K & 63) == 0) {
             static const bool no_remap = getenv("WM_GEMM_NOXCD") != nullptr;
             GemmParams q = p;
