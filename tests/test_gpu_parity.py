@@ -84,6 +84,29 @@ def test_op_matmul_bf16_rounding(hip):
     assert np.abs(out - Ab @ Bb.T).max() < 1e-4
 
 
+@pytest.mark.parametrize("M,N", [(4741, 1152), (20000, 3072), (130, 128)])
+def test_op_matmul_rowpanel_bf16(hip, M, N):
+    """K = 384 with 16-bit operands runs on the A-stationary row-panel kernel (counted-vmcnt LDS ring, several units and
+    panel switches per workgroup, ragged last panel): exact products of the rounded operands, and the same bits every time."""
+    import torch
+    from whisper_mojo_amd import whisper_tensor as wt, DT_BF16
+    r = np.random.default_rng(M + N)
+    A, B = r.standard_normal((M, 384), np.float32), r.standard_normal((N, 384), np.float32)
+    bias = r.standard_normal(N, np.float32)
+    Ab = torch.from_numpy(A).bfloat16().float().numpy()
+    Bb = torch.from_numpy(B).bfloat16().float().numpy()
+    ref = Ab.astype(np.float64) @ Bb.T.astype(np.float64) + bias
+    first = None
+    for _ in range(3):
+        out = wt.Tensor(M, N)
+        wt.matmul(out, A, B, bias, dtype=DT_BF16)
+        assert np.abs(out - ref).max() < 2e-4
+        if first is None:
+            first = out.copy()
+        else:
+            assert np.array_equal(out, first)
+
+
 def test_op_layer_norm(hip, oracle_mod):
     from whisper_mojo_amd import whisper_tensor as wt
     for rows, cols in ((9, 384), (1, 128), (70, 512)):
