@@ -106,11 +106,16 @@ struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
     int alloc(size_t n, bool zero = false) {
+        release();  // re-allocation never leaks the previous block
         bytes = n ? n : 16;
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) return fail(WM_E_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
         if (zero) {
+            // hipMemset on device memory is asynchronous to the host and runs on the null stream, which the library's
+            // non-blocking streams do not wait for: finish it here, or the first kernels on a fresh buffer can race the
+            // zeroing (seen once in ~6 runs of the eight-slot test as a wrong token row)
             e = hipMemset(p, 0, bytes);
+            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
             if (e != hipSuccess) return fail(WM_E_HIP, "hipMemset: %s", hipGetErrorString(e));
         }
         return 0;
