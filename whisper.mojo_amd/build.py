@@ -53,5 +53,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_examples(force: bool = False) -> str:
+    """examples/whisper_main: main.mojo written against include/whisper_mi.hpp (the C++ host mirror), linked to the library."""
+    root = os.path.dirname(HERE)
+    src, hdr = os.path.join(root, "examples", "main.cpp"), os.path.join(root, "include", "whisper_mi.hpp")
+    exe = os.path.join(root, "examples", "whisper_main")
+    if not force and os.path.exists(exe) and all(os.path.getmtime(f) <= os.path.getmtime(exe) for f in (src, hdr, LIB)):
+        return exe
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise RuntimeError("no C++ compiler for examples/main.cpp")
+    subprocess.check_call([cxx, "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", os.path.join(root, "include"), src, "-o", exe,
+                           "-L", CSRC, "-lwhispermi", "-Wl,-rpath," + CSRC, "-Wl,-rpath,$ORIGIN/../whisper.mojo_amd/csrc"])
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_examples(force="--force" in sys.argv))
