@@ -83,3 +83,38 @@ def test_gpu_front_end_micro_config(micro_cfg, micro_weights):
     for i, a in enumerate(audios):
         ref = lo.log_mel(a, n_frames=micro_cfg.n_frames, n_mels=micro_cfg.n_mels)
         assert np.abs(mels[i] - ref).max() < 2e-3
+
+
+@pytest.mark.gpu
+def test_long_form_and_language_id(micro_cfg, micro_weights):
+    """§8f rank 4, host level: long audio = consecutive full windows through the batch path (ids equal per-window
+    transcription); language id = one decoder step on the start token, softmax over a range of ids (checked against the
+    oracle's logits for the same step)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import logmel_oracle as lo, oracle
+    from whisper_mojo_amd import frontend
+    from whisper_mojo_amd.loader import WeightLoader
+    from whisper_mojo_amd.whisper import Whisper
+    m = Whisper(micro_cfg, max_batch=2)
+    m.load(WeightLoader.from_array(micro_weights))
+    win = micro_cfg.n_frames * frontend.HOP
+    audio = lo.synth_audio(21, 3 * win + 5000)  # 3 full windows + a short tail -> 4 windows, 2 batches of 2
+    kw = dict(prompt=(1, 2, 3, 4), eot=-1, max_loop=6)
+    per_window, flat = frontend.transcribe_long(m, audio, **kw)
+    assert len(per_window) == 4
+    for i, ids in enumerate(per_window):
+        assert ids == frontend.transcribe_audio(m, [audio[i * win:(i + 1) * win]], **kw)[0]
+    assert flat == [t for ids in per_window for t in ids[4:]]
+    # language id on the micro vocabulary: "languages" = ids 100..131
+    mel = frontend.log_mel(m, [audio[:win]])[0]
+    lid, p = frontend.detect_language(m, mel, sot=7, lang_first=100, lang_last=131)
+    ref = oracle.OracleModel(micro_cfg, micro_weights)
+    _, logits = ref.transcribe(mel=mel, prompt=(7,), eot=-1, max_loop=0, want_logits=True)
+    rl = logits[0][100:132].astype(np.float64)
+    rp = np.exp(rl - rl.max()); rp /= rp.sum()
+    assert lid == 100 + int(rp.argmax()) and abs(p.sum() - 1) < 1e-9
+    assert np.abs(p - rp).max() < 1e-4
+    ids, pb = frontend.detect_language(m, np.stack([mel, mel]), sot=7, lang_first=100, lang_last=131)
+    assert ids.tolist() == [lid, lid] and np.allclose(pb[0], p) and np.allclose(pb[1], p)

@@ -47,3 +47,48 @@ def transcribe_audio(model, audios: Sequence[np.ndarray], prompt: Sequence[int] 
     _lib.check(_lib.lib().wm_transcribe_pcm(model._h, buf.ctypes.data_as(fp), n.ctypes.data_as(ip), len(audios), stride,
                                             C.byref(opts), toks.ctypes.data_as(ip), cnt.ctypes.data_as(ip)))
     return [toks[b, :cnt[b]].tolist() for b in range(len(audios))]
+
+
+# ---- decoding features the reference lacks, host-level over the same C-ABI -----------------------
+HOP = 160  # samples per mel frame (WhisperFeatureExtractor hop_length)
+
+
+def transcribe_long(model, audio: np.ndarray, prompt: Sequence[int] = PROMPT, eot: int = EOT, max_loop: int = MAX_LOOP,
+                    suppress_tokens: Sequence[int] = (), begin_suppress_tokens: Sequence[int] = ()):
+    """Long-form audio by consecutive 30 s windows (the reference handles one 30 s clip, main.mojo:22-27): the windows
+    are independent utterances, so they go through the batch path `max_batch` at a time.  Returns (per-window id lists
+    exactly as `transcribe` would give them, generated ids of all windows concatenated without prompt / eot)."""
+    audio = np.asarray(audio, np.float32).ravel()
+    win = model.config.n_frames * HOP  # 480 000 samples = 30 s for the released models
+    n_win = max(1, -(-len(audio) // win))
+    windows = [audio[i * win:(i + 1) * win] for i in range(n_win)]
+    per_window: List[List[int]] = []
+    for i in range(0, n_win, model.max_batch):
+        group = windows[i:i + model.max_batch]
+        mels = log_mel(model, group)
+        per_window += model.transcribe_batch(mels, prompt=prompt, eot=eot, max_loop=max_loop,
+                                             suppress_tokens=suppress_tokens, begin_suppress_tokens=begin_suppress_tokens)
+    flat: List[int] = []
+    for ids in per_window:
+        gen = ids[len(prompt):]
+        flat += gen[:-1] if gen and gen[-1] == eot else gen
+    return per_window, flat
+
+
+def detect_language(model, mel, sot: int = 50258, lang_first: int = 50259, lang_last: int = 50357):
+    """Whisper's language identification: one decoder step on <|startoftranscript|> and a softmax restricted to the
+    language ids (multilingual vocabulary: 50259..50357).  mel: [n_mels, 3000] or [B, n_mels, 3000].
+    Returns (ids [B], probabilities [B, n_lang])."""
+    from .whisper import KVCache
+    m = np.asarray(mel, np.float32)
+    batched = m.ndim == 3
+    m = m if batched else m[None]
+    B = m.shape[0]
+    cache = KVCache(model, B)
+    model.encoder.forward(m, cache)
+    logits = model.decoder.forward(np.full((B, 1), sot, np.int32), None, cache, start_pos=0)
+    lang = np.asarray(logits, np.float64).reshape(B, -1)[:, lang_first:lang_last + 1]
+    p = np.exp(lang - lang.max(1, keepdims=True))
+    p /= p.sum(1, keepdims=True)
+    ids = lang_first + p.argmax(1)
+    return (ids, p) if batched else (int(ids[0]), p[0])
