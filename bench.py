@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # The pipelined passes decode on one HIP stream each; ROCm multiplexes streams onto GPU_MAX_HW_QUEUES (default 4)
 # hardware queues, and two passes that share a queue run one after the other.  Must be set before HIP initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 WORKLOADS = {
     #  name             (config, B/GPU, compute, kv)

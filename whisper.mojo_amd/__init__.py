@@ -8,7 +8,7 @@ import os as _os
 
 # One HIP stream per pipeline slot (wm_transcribe_submit): ROCm multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
 # (default 4) and passes that share a queue serialise.  Only effective if set before the HIP runtime initialises.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from .config import (WhisperConfig, GELU_TANH, GELU_ERF, POS_REF, POS_HF, DT_F32, DT_BF16, DT_F16, PROMPT, EOT,
                      MAX_LOOP)
