@@ -140,10 +140,10 @@ def main():
     mel_dev = torch.from_numpy(mel_host).to(dev)  # resident in HBM before the timed region
     stride = 4 + 1 + DECODE_STEPS
 
-    # Steps are issued through the library's pipeline slots (wm_transcribe_submit / _wait): step k+1 is submitted
-    # before step k's ids are collected, so its MFMA-bound encoder overlaps step k's latency/HBM-bound decode, and the
-    # token all-gather of step k overlaps step k+1 entirely.  Every step still does the full work; all K steps are
-    # complete (ids on the host, gathered) before the timed region closes.  --no-pipeline runs them one after another.
+    # Steps are issued through the library's pipeline slots (wm_transcribe_submit / _wait), `--pipeline` of them in flight:
+    # their encoders share the chip, then their latency/HBM-bound decode chains do.  Every step still does the full work;
+    # all K steps are complete (ids on the host, gathered) before the timed region closes.  --no-pipeline runs them one
+    # after another.
     def run_steps(n):
         out = None
         if args.no_pipeline:
@@ -151,16 +151,21 @@ def main():
                 model.transcribe_batch(mel_dev, max_loop=DECODE_STEPS, ignore_eot=True)
                 out = wdist.gather_tokens(model.last_tokens, model.last_counts, total, stride)
             return out
-        depth, inflight = args.pipeline, []
-        for k in range(n):
-            if len(inflight) == depth:  # oldest step: collect its ids (+ all-gather) before its slot is reused
-                model.transcribe_wait(inflight.pop(0))
-                out = wdist.gather_tokens(model.last_tokens, model.last_counts, total, stride)
-            model.transcribe_submit(mel_dev, slot=k % depth, max_loop=DECODE_STEPS, ignore_eot=True)
-            inflight.append(k % depth)
-        while inflight:
-            model.transcribe_wait(inflight.pop(0))
-            out = wdist.gather_tokens(model.last_tokens, model.last_counts, total, stride)
+        # Groups of `depth` passes: submit them all, collect them all, THEN all-gather.  Four passes on four streams fill
+        # the four hardware queues the chip runs at a time and finish together anyway; an RCCL kernel issued while a slot's
+        # queue is busy could land on that queue's pipe and sit behind a whole pass, so the gathers go where the GPU is idle.
+        depth, k = args.pipeline, 0
+        while k < n:
+            g = min(depth, n - k)
+            for sl in range(g):
+                model.transcribe_submit(mel_dev, slot=sl, max_loop=DECODE_STEPS, ignore_eot=True)
+            done = []
+            for sl in range(g):
+                model.transcribe_wait(sl)
+                done.append((model.last_tokens, model.last_counts))
+            for toks, cnts in done:
+                out = wdist.gather_tokens(toks, cnts, total, stride)
+            k += g
         return out
 
     def sync():
