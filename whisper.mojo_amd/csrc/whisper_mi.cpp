@@ -160,7 +160,7 @@ struct wm_model {
     int Vpad = 0;
     // utterances per encoder pass.  Measured (tiny, B=64, ms per 64 clips): 4 -> 12.0, 8 -> 9.0, 16 -> 7.6, 32 -> 6.8,
     // 64 -> 6.7: filling the chip (>= 4 tiles per CU per launch) matters more than keeping activations in the 256 MB L3
-    int enc_chunk = 32;
+    int enc_chunk = 64;  // (re-measured with the row-panel GEMMs: 16 -> 6.1, 32 -> 5.0, 64 -> 4.8 ms)
     DevBuf conv1_w, conv1_b, conv2_w, conv2_b, enc_pos;
     std::vector<EncLayer> enc;
     DevBuf enc_ln_g, enc_ln_b;
