@@ -778,19 +778,21 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_enc_v2_kernel(const T* __r
         Frag<T> pf[QB][2];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
+            // running max kept in the exp2 domain (score * scale * log2 e); the per-score scaling rides the exp2 argument as
+            // one fma.  (Rescaling the accumulator only when a row's max moved was measured neutral and is not done.)
             float tmax = -1e30f;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = sc[qb][kb][r] * scale_log2e;
+                    float v = sc[qb][kb][r];
                     if (last && t * 64 + kb * 16 + g * 4 + r >= n_ctx) v = -1e30f;
                     sc[qb][kb][r] = v;
                     tmax = fmaxf(tmax, v);
                 }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run[qb], tmax);
+            const float m_new = fmaxf(m_run[qb], tmax * scale_log2e);
             const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
             m_run[qb] = m_new;
             float psum = 0.f;
@@ -799,7 +801,7 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_enc_v2_kernel(const T* __r
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pe = __builtin_amdgcn_exp2f(sc[qb][kb][r] - m_new);
+                    const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qb][kb][r], scale_log2e, -m_new));
                     psum += pe;
                     pv[kb >> 1][(kb & 1) * 4 + r] = pe;
                 }
