@@ -1571,9 +1571,14 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
         for (int i = 0; i < reps; ++i) launch_cross_attn(m, s, i % L, v);  // cycles the layers: 4 x 295 MB > 256 MB L3
         HIPCHK(hipEventRecord(e1, st));
     } else if (which == WM_KERNEL_DECODE_STEP) {
+        // on the state's own decode stream, as the transcribe loop runs it: several states can be timed concurrently
+        // from several host threads (bench.py: four chains in flight)
         const int len0 = std::max(s->host_len, 1);
-        const DecView v = whole_batch(m, s);
-        launch_set_step(s->ctl.as<StepCtl>(), len0, 1, nullptr, 0, nullptr, 0, s->B, st);
+        HIPCHK(hipStreamSynchronize(m->stream));  // wm_encode ran there
+        const bool own = s->lanes.size() == 1;      // (WM_DEC_LANES > 1: whole batch on the model stream as before)
+        if (own) st = s->lanes[0].st;
+        const DecView v{0, s->B, st, own ? s->lanes[0].ctl : s->ctl.as<StepCtl>()};
+        launch_set_step(v.ctl, len0, 1, nullptr, 0, nullptr, 0, s->B, st);
         decode_core(m, s, v, true);
         // timed as the transcribe loop runs it: a captured graph of the step, replayed (cache length held constant)
         hipGraph_t g = nullptr;
