@@ -688,7 +688,10 @@ __device__ __forceinline__ f16x4 lds_tr16(const f16* p) {
 template <typename T, int NW, int QB>
 __global__ __launch_bounds__(NW * 64) void flash_attn_enc_v2_kernel(const T* __restrict__ qkv, T* __restrict__ out, int n_ctx,
                                                                     int d_model, float scale_log2e, int xcd_remap) {
-    constexpr int PITCH = 72;  // 144-byte rows: conflict-free ds_read_b128 fragments and tr reads
+    // 160-byte rows (40 dwords): with the hardware's lane groups (ds_read_b128: {0-3,12-15,20-27}, ...; ds_read_b64_tr:
+    // 32 lanes = 8 rows x 32 B) the 16 fragment rows / 8 transposed rows of one access fall on disjoint banks.  (144-byte
+    // rows had 2-way conflicts on both: 6 % of the kernel's wave cycles in SQ_LDS_BANK_CONFLICT.)
+    constexpr int PITCH = 80;
     __shared__ __attribute__((aligned(16))) T Ks[2][64 * PITCH];
     __shared__ __attribute__((aligned(16))) T Vs[2][64 * PITCH];
     typedef __attribute__((ext_vector_type(8))) T t8;
