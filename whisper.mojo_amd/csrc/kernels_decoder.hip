@@ -241,7 +241,10 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
     // (51 865 rows: CT = 13 -> 250 workgroups, 160 KB of embedding rows per CU): the kernel is a single pass over the
     // embedding at one workgroup per CU instead of 406 128-column workgroups in two rounds (16.5 -> ~10 us).
     constexpr int K = KD * 128;
-    constexpr int PAD = 16 / sizeof(TW);
+    // row pitch of the LDS activation image: for 16-bit operands ≡ 40 dwords (mod 64) — with the hardware's ds_read_b128
+    // lane groups ({0-3,12-15,20-27}, ...) the 16 fragment rows of one read then sit on disjoint banks (a 4-dword pad
+    // left one 2-way conflict per group: 3 % of the kernel's wave cycles in SQ_LDS_BANK_CONFLICT)
+    constexpr int PAD = sizeof(TW) == 2 ? 80 - (K % 128) : 16 / sizeof(TW);
     constexpr int PITCH = K + PAD;
     constexpr int KS = KD * 4;                         // k-steps of 32
     constexpr int CHK = sizeof(TW) == 2 ? KS : KS / 2;  // k-steps whose weight fragments are in flight together
@@ -434,7 +437,7 @@ int dec_logits_parts(int N) {
     return (tiles + ct - 1) / ct;
 }
 template <typename TW, int KD, int NRB> static void launch_dec_logits_t(const DecLinearParams& p, hipStream_t st) {
-    const size_t lds = (size_t)NRB * 16 * (KD * 128 + 16 / sizeof(TW)) * sizeof(TW);
+    const size_t lds = (size_t)NRB * 16 * (KD * 128 + (sizeof(TW) == 2 ? 80 : 16 / sizeof(TW))) * sizeof(TW);
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_logits_kernel<TW, KD, NRB>),
