@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--workload", default="tiny_b64_bf16", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-x4", action="store_true", help="skip the four-chains-in-flight decode step timing (profiler runs: keeps every launch of the dominant kernel alone on the chip)")
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after another")
     ap.add_argument("--pipeline", type=int, default=4, choices=[1, 2, 3, 4, 5, 6, 7, 8], help="steps in flight (library pipeline slots)")
     args = ap.parse_args()
@@ -227,31 +228,33 @@ def main():
         log("kernel timing: decode step")
         _lib.check(L.wm_bench_kernel(model._h, st, _lib.KERNEL_DECODE_STEP, 50, C.byref(step_us)))
         _lib.check(L.wm_bench_bytes(model._h, st, _lib.KERNEL_DECODE_STEP, C.byref(step_bytes)))
-        # the same step with four passes decoding at once (what the pipelined rate runs on): four states, four host threads
-        log("kernel timing: decode step, four chains in flight")
-        import threading
-        sts = [st]
-        for _ in range(3):
-            s2 = C.c_void_p()
-            _lib.check(L.wm_state_new(model._h, count, C.byref(s2)))
-            _lib.check(L.wm_encode(model._h, s2, C.c_void_p(mel_dev.data_ptr()), 1, count, None))
-            sts.append(s2)
-        us4 = [C.c_float() for _ in sts]
-        errs = []
+        step4_us = None
+        if not args.no_x4:
+            # the same step with four passes decoding at once (what the pipelined rate runs on): four states, four host threads
+            log("kernel timing: decode step, four chains in flight")
+            import threading
+            sts = [st]
+            for _ in range(3):
+                s2 = C.c_void_p()
+                _lib.check(L.wm_state_new(model._h, count, C.byref(s2)))
+                _lib.check(L.wm_encode(model._h, s2, C.c_void_p(mel_dev.data_ptr()), 1, count, None))
+                sts.append(s2)
+            us4 = [C.c_float() for _ in sts]
+            errs = []
 
-        def _chain(i):
-            try:
-                _lib.check(L.wm_bench_kernel(model._h, sts[i], _lib.KERNEL_DECODE_STEP, 100, C.byref(us4[i])))
-            except Exception as e:  # noqa: BLE001
-                errs.append(e)
-        th = [threading.Thread(target=_chain, args=(i,)) for i in range(4)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-        if errs:
-            raise errs[0]
-        step4_us = max(u.value for u in us4)
-        for s2 in sts[1:]:
-            L.wm_state_free(s2)
+            def _chain(i):
+                try:
+                    _lib.check(L.wm_bench_kernel(model._h, sts[i], _lib.KERNEL_DECODE_STEP, 100, C.byref(us4[i])))
+                except Exception as e:  # noqa: BLE001
+                    errs.append(e)
+            th = [threading.Thread(target=_chain, args=(i,)) for i in range(4)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            if errs:
+                raise errs[0]
+            step4_us = max(u.value for u in us4)
+            for s2 in sts[1:]:
+                L.wm_state_free(s2)
         log("kernel timing: encoder")
         _lib.check(L.wm_bench_kernel(model._h, st, _lib.KERNEL_ENCODER, 3, C.byref(enc_us)))
         L.wm_state_free(st)
@@ -277,11 +280,12 @@ def main():
                          "bytes_per_launch": nbytes.value, "us_per_launch": round(us.value, 2)},
             "decode_step": {"us": round(step_us.value, 1), "algorithmic_bytes": step_bytes.value,
                             "GBps": round(step_gbs, 1), "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
-            "decode_step_4_in_flight": {"us_per_step_of_each_chain": round(step4_us, 1),
-                                        "aggregate_GBps": round(4 * step_bytes.value / (step4_us * 1e-6) / 1e9, 1),
-                                        "frac_of_hbm_peak": round(4 * step_bytes.value / (step4_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
             "encoder": {"ms": round(enc_us.value / 1e3, 3), "TFLOPs": round(enc_flops / (enc_us.value * 1e-6) / 1e12, 1)},
         }
+        if step4_us is not None:
+            res["decode_step_4_in_flight"] = {"us_per_step_of_each_chain": round(step4_us, 1),
+                                              "aggregate_GBps": round(4 * step_bytes.value / (step4_us * 1e-6) / 1e9, 1),
+                                              "frac_of_hbm_peak": round(4 * step_bytes.value / (step4_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline (oracle) ...")
             res["cpu_baseline"] = cpu_baseline(cfg, weights, mel_host[0], DECODE_STEPS)
