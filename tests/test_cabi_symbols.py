@@ -48,3 +48,11 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("test_oracle", ""), f"{f} mentions the oracle"
+
+
+def test_package_import_sets_hw_queue_default():
+    """Pipelined passes need one hardware queue per slot stream: the package sets GPU_MAX_HW_QUEUES before HIP
+    initialises unless the user already chose a value."""
+    import os
+    import whisper_mojo_amd  # noqa: F401
+    assert int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) >= 8
