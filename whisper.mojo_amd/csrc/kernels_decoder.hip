@@ -173,7 +173,8 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
         if (p.kcache && en >= p.d_model) {
             const bool is_v = en >= 2 * p.d_model;
             const int cc = en - (is_v ? 2 : 1) * p.d_model;
-            const size_t off = (size_t)eb * p.kv_batch_stride + (size_t)cache_row * p.d_model + cc;
+            const int ub = p.kv_B > 0 ? eb % p.kv_B : eb, ut = p.kv_B > 0 ? eb / p.kv_B : 0;  // prefill rows: (position, utterance)
+            const size_t off = (size_t)ub * p.kv_batch_stride + (size_t)(cache_row + ut) * p.d_model + cc;
             void* basep = is_v ? p.vcache : p.kcache;
             if (p.kv_dtype == 0) {
                 *reinterpret_cast<f32x4*>((float*)basep + off) = v;
@@ -476,8 +477,10 @@ template void launch_dec_logits<f16>(const DecLinearParams&, hipStream_t);
 // attn_combine, or the normalised output directly when the chunk is the whole sequence.
 // Scale after the dot product and max initialised to -1e10 follow layers.mojo:196,212 (the mask branch at :213 is a
 // no-op for j <= len-1 and is omitted).
-template <typename TKV, int LPH, bool FAST, bool NT, int U>
+template <typename TKV, int LPH, bool FAST, bool NT, int U, int NQ = 1>
 __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecParams p) {
+    // NQ > 1 (prompt prefill, cross-attention): the workgroup of utterance b serves the NQ query rows t * B + b from ONE
+    // sweep of that utterance's K/V chunk — each cache row is read once for all prompt positions.
     constexpr int EPL = 64 / LPH;  // elements per lane
     __shared__ float s_ml[512][2];
     __shared__ float s_red[512 * EPL];
@@ -485,7 +488,9 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecParams p) {
     if (p.ts && NT && b == 0 && split == 0 && threadIdx.x == 0) ts_put(p.ts, p.ts_id, 0);
     const int LPR = p.H * LPH;
     const int RPS = p.rps;  // key rows swept per step = active threads / LPR
-    const int len = p.n_keys >= 0 ? p.n_keys : p.ctl->len + 1;
+    const int bk = (NQ == 1 && p.q_B > 0) ? b % p.q_B : b;  // utterance whose K/V this workgroup reads
+    const int len = p.n_keys >= 0 ? p.n_keys : p.ctl->len + 1 + ((NQ == 1 && p.q_B > 0) ? b / p.q_B : 0);
+    const int qstride = NQ > 1 ? p.q_B : 0;  // query / output row of position t: b + t * qstride
     const int chunk = (len + p.nsplit - 1) / p.nsplit;
     const int j0 = split * chunk;
     const int j1 = min(len, j0 + chunk);
@@ -493,17 +498,24 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecParams p) {
     const int h = c / LPH, e0 = (c % LPH) * EPL;
     const bool active = rslot < RPS;
 
-    float qv[EPL];
+    float qv[NQ][EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) qv[e] = p.q[(size_t)b * p.d + h * 64 + e0 + e] * p.scale;
-    const TKV* Kb = (const TKV*)p.K + (size_t)b * p.batch_stride + h * 64 + e0;
-    const TKV* Vb = (const TKV*)p.V + (size_t)b * p.batch_stride + h * 64 + e0;
+    for (int t = 0; t < NQ; ++t)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) qv[t][e] = p.q[(size_t)(b + t * qstride) * p.d + h * 64 + e0 + e] * p.scale;
+    const TKV* Kb = (const TKV*)p.K + (size_t)bk * p.batch_stride + h * 64 + e0;
+    const TKV* Vb = (const TKV*)p.V + (size_t)bk * p.batch_stride + h * 64 + e0;
     typedef __attribute__((ext_vector_type(EPL))) TKV kvec;
 
-    float m_run = -1e10f, l_run = 0.f;
-    float acc[EPL];
+    float m_run[NQ], l_run[NQ];
+    float acc[NQ][EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    for (int t = 0; t < NQ; ++t) {
+        m_run[t] = -1e10f;
+        l_run[t] = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[t][e] = 0.f;
+    }
     const int step = RPS * U;
 
     auto load = [&](kvec (&kk)[U], kvec (&vv)[U], int j) {
@@ -520,31 +532,34 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecParams p) {
         }
     };
     auto consume = [&](const kvec (&kk)[U], const kvec (&vv)[U], int j) {
-        float sc[U];
-        float bm = -1e30f;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float dot = 0.f;
+        for (int t = 0; t < NQ; ++t) {
+            float sc[U];
+            float bm = -1e30f;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) dot += qv[e] * (float)kk[u][e];
-            dot = LPH == 16 ? group_sum16(dot) : group_sum8(dot);
-            sc[u] = (active && j + u * RPS < j1) ? dot : -1e30f;
-            bm = fmaxf(bm, sc[u]);
+            for (int u = 0; u < U; ++u) {
+                float dot = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) dot += qv[t][e] * (float)kk[u][e];
+                dot = LPH == 16 ? group_sum16(dot) : group_sum8(dot);
+                sc[u] = (active && j + u * RPS < j1) ? dot : -1e30f;
+                bm = fmaxf(bm, sc[u]);
+            }
+            const float m_new = fmaxf(m_run[t], bm);
+            const float alpha = FAST ? __expf(m_run[t] - m_new) : expf(m_run[t] - m_new);
+            float ps = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[t][e] *= alpha;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float pe = FAST ? __expf(sc[u] - m_new) : expf(sc[u] - m_new);
+                ps += pe;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) acc[t][e] += pe * (float)vv[u][e];
+            }
+            l_run[t] = l_run[t] * alpha + ps;
+            m_run[t] = m_new;
         }
-        const float m_new = fmaxf(m_run, bm);
-        const float alpha = FAST ? __expf(m_run - m_new) : expf(m_run - m_new);
-        float ps = 0.f;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) acc[e] *= alpha;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float pe = FAST ? __expf(sc[u] - m_new) : expf(sc[u] - m_new);
-            ps += pe;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) acc[e] += pe * (float)vv[u][e];
-        }
-        l_run = l_run * alpha + ps;
-        m_run = m_new;
     };
 
     {
@@ -566,34 +581,39 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecParams p) {
             }
         }
     }
-    // merge the RPS row slots (lanes of one LPH group carry identical m, l)
-    s_ml[threadIdx.x][0] = m_run;
-    s_ml[threadIdx.x][1] = l_run;
+    // merge the RPS row slots (lanes of one LPH group carry identical m, l), one query position after the other
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) s_red[threadIdx.x * EPL + e] = acc[e];
-    __syncthreads();
-    if (rslot == 0) {
-        float M = -1e10f;
-        for (int r = 0; r < RPS; ++r) M = fmaxf(M, s_ml[r * LPR + c][0]);
-        float L = 0.f, o[EPL];
+    for (int t = 0; t < NQ; ++t) {
+        if (t > 0) __syncthreads();  // everyone is done reading the previous position's partials
+        s_ml[threadIdx.x][0] = m_run[t];
+        s_ml[threadIdx.x][1] = l_run[t];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) o[e] = 0.f;
-        for (int r = 0; r < RPS; ++r) {
-            const int t = r * LPR + c;
-            const float wgt = s_ml[t][1] > 0.f ? (FAST ? __expf(s_ml[t][0] - M) : expf(s_ml[t][0] - M)) : 0.f;
-            L += wgt * s_ml[t][1];
+        for (int e = 0; e < EPL; ++e) s_red[threadIdx.x * EPL + e] = acc[t][e];
+        __syncthreads();
+        if (rslot == 0) {
+            float M = -1e10f;
+            for (int r = 0; r < RPS; ++r) M = fmaxf(M, s_ml[r * LPR + c][0]);
+            float L = 0.f, o[EPL];
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) o[e] += wgt * s_red[t * EPL + e];
-        }
-        float* po = p.direct_out ? p.direct_out + (size_t)b * p.d + h * 64 + e0
-                                 : p.part_o + ((size_t)b * p.nsplit + split) * p.d + h * 64 + e0;
-        const float norm = p.direct_out ? 1.0f / L : 1.0f;
+            for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+            for (int r = 0; r < RPS; ++r) {
+                const int tt = r * LPR + c;
+                const float wgt = s_ml[tt][1] > 0.f ? (FAST ? __expf(s_ml[tt][0] - M) : expf(s_ml[tt][0] - M)) : 0.f;
+                L += wgt * s_ml[tt][1];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) po[e] = o[e] * norm;
-        if (!p.direct_out && (c % LPH) == 0) {
-            float* pml = p.part_ml + (((size_t)b * p.nsplit + split) * p.H + h) * 2;
-            pml[0] = M;
-            pml[1] = L;
+                for (int e = 0; e < EPL; ++e) o[e] += wgt * s_red[tt * EPL + e];
+            }
+            const size_t orow = (size_t)b + (size_t)t * qstride;
+            float* po = p.direct_out ? p.direct_out + orow * p.d + h * 64 + e0
+                                     : p.part_o + (orow * p.nsplit + split) * p.d + h * 64 + e0;
+            const float norm = p.direct_out ? 1.0f / L : 1.0f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) po[e] = o[e] * norm;
+            if (!p.direct_out && (c % LPH) == 0) {
+                float* pml = p.part_ml + ((orow * p.nsplit + split) * p.H + h) * 2;
+                pml[0] = M;
+                pml[1] = L;
+            }
         }
     }
 }
@@ -612,6 +632,11 @@ template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStrea
     const dim3 grid(p.nsplit, p.B), block((q.rps * LPR + 63) / 64 * 64);
     static const bool nt_off = getenv("WM_NO_NT") != nullptr;
     static const int u_cross = getenv("WM_ATTN_U") ? atoi(getenv("WM_ATTN_U")) : 4;
+    if (p.n_keys >= 0 && p.nq == 4) {  // prompt prefill, four positions per utterance from one K/V sweep (q_B = utterances)
+        const dim3 grid4(p.nsplit, p.q_B);
+        hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 4, 4>), grid4, block, 0, st, q);  // U = 4 as in the step kernel: same arithmetic per query
+        return;
+    }
     if (p.n_keys >= 0 && !nt_off) {  // the cross-attention K/V stream (1500 rows per utterance, read once per step)
         if (u_cross == 8)
             hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 8>), grid, block, 0, st, q);
@@ -797,6 +822,12 @@ __global__ void init_tokens_kernel(InitTokensParams p) {
         for (int i = 0; i < p.n_prompt; ++i) p.out_tokens[(size_t)b * p.out_stride + i] = p.prompt[i];
         p.n_tokens[b] = p.n_prompt;
         p.finished[b] = 0;
+        if (p.tok_rows) {
+            for (int i = 0; i < p.n_prompt; ++i) {
+                p.tok_rows[i * p.B + b] = p.prompt[i];
+                p.pos_rows[i * p.B + b] = i;
+            }
+        }
     }
     if (b == 0) {
         p.ctl->len = 0;

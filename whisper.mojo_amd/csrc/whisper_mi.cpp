@@ -217,7 +217,8 @@ struct wm_state {
     DevBuf mask_steady, mask_begin;  // [Vpad] additive logit masks (0 / -inf) for the fused argmax
     std::vector<int32_t> sup_cached, bsup_cached;
     bool masks_valid = false;
-    DevBuf dx, dq, dattn, dhid, part_o, part_ml, logits, amax_val, amax_idx, tok, pos, ctl, out_tokens, n_tokens, finished;
+    static const int PREFILL_MAX = 16;  // prompt positions decoded in one pass (= the n_prompt bound of wm_decode_opts)
+    DevBuf dx, dq, dattn, dhid, part_o, part_ml, logits, amax_val, amax_idx, tok, pos, tok_rows, pos_rows, ctl, out_tokens, n_tokens, finished;
     int npart = 0;  // fused-argmax partials per utterance = workgroups per row block of the logits kernel
 };
 
@@ -637,7 +638,7 @@ extern "C" void wm_state_free(wm_state* s) {
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     DevBuf* bs[] = {&s->mel_dev, &s->mel_t, &s->h1, &s->x, &s->xn, &s->qkv, &s->ao, &s->hid, &s->enc_t, &s->enc_f,
                     &s->cross_kv, &s->self_kv, &s->dx, &s->dq, &s->dattn, &s->dhid, &s->part_o, &s->part_ml, &s->logits, &s->amax_val, &s->amax_idx, &s->mask_steady, &s->mask_begin,
-                    &s->tok, &s->pos, &s->ctl, &s->out_tokens, &s->n_tokens, &s->finished};
+                    &s->tok, &s->pos, &s->tok_rows, &s->pos_rows, &s->ctl, &s->out_tokens, &s->n_tokens, &s->finished};
     for (DevBuf* b : bs) b->release();
     delete s;
 }
@@ -687,12 +688,16 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
     A(s->enc_f, (size_t)B * T * d * 4);
     A(s->cross_kv, (size_t)c.n_layers * 2 * B * T * d * ks);
     A(s->self_kv, (size_t)c.n_layers * 2 * B * c.n_text_ctx * d * ks, true);
-    A(s->dx, (size_t)B * d * 4);
-    A(s->dq, (size_t)B * d * 4);
-    A(s->dattn, (size_t)B * d * 4);
-    A(s->dhid, (size_t)B * c.ffn * 4);
-    A(s->part_o, (size_t)B * s->nsplit * d * 4);
-    A(s->part_ml, (size_t)B * s->nsplit * c.n_heads * 2 * 4);
+    // decode activations: rows for one token per utterance, or — prompt prefill — for up to PREFILL_MAX positions at once
+    const size_t R = (size_t)B * wm_state::PREFILL_MAX;
+    A(s->dx, R * d * 4);
+    A(s->dq, R * d * 4);
+    A(s->dattn, R * d * 4);
+    A(s->dhid, R * c.ffn * 4);
+    A(s->part_o, R * s->nsplit * d * 4);
+    A(s->part_ml, R * s->nsplit * c.n_heads * 2 * 4);
+    A(s->tok_rows, R * 4, true);
+    A(s->pos_rows, R * 4, true);
     A(s->logits, (size_t)B * m->Vpad * 4);
     s->npart = dec_logits_parts(c.vocab);
     A(s->amax_val, (size_t)B * s->npart * 4);
@@ -966,7 +971,7 @@ struct DecView {
 };
 static DecView whole_batch(wm_model* m, wm_state* s) { return DecView{0, s->B, m->stream, s->ctl.as<StepCtl>()}; }
 
-static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v) {
+static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v, int P = 1) {
     const wm_dims& c = m->cfg.dims;
     const size_t d = c.d_model, ks = dt_size(m->cfg.kv_dtype);
     const size_t cross_l = (size_t)s->B * c.n_audio_ctx * d;
@@ -984,7 +989,10 @@ static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v)
     a.part_ml = s->part_ml.as<float>() + (size_t)v.b0 * s->nsplit * c.n_heads * 2;
     a.H = c.n_heads;
     a.d = c.d_model;
-    a.B = v.nb;
+    a.B = v.nb * P;
+    a.q_B = P > 1 ? v.nb : 0;
+    static const bool no_mq = getenv("WM_NO_MQ_PREFILL") != nullptr;
+    a.nq = (P == 4 && !no_mq) ? 4 : 0;  // the reference's 4-token prompt: one K/V sweep for the four positions
     a.ts = (long long*)m->ts_buf.p;
     a.ts_id = s->trace_id;
     attn_decode_dispatch(m->cfg.kv_dtype, a, v.st);
@@ -992,11 +1000,16 @@ static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v)
 
 // want_logits: run the final LN + vocabulary projection.  full_logits: also materialise [B, vocab] fp32 (stage tests,
 // wm_decode_step); the greedy loop only needs the fused-argmax partials.
+// P > 1: prompt prefill — P positions of every utterance in ONE pass (whisper.mojo:195: the q_len = n_prompt block).  Rows are
+// position-major (row = t * B + b), tokens / positions come from tok_rows / pos_rows, K/V rows go to cache rows len + t, the
+// self-attention of position t sees keys 0..len+t (the causal mask of layers.mojo:309-318), logits only for the last
+// position.  Every row's arithmetic is what the single-position pass does for it, so the ids are the same bit for bit.
 static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_logits, bool full_logits = false,
-                        const float* mask = nullptr) {
+                        const float* mask = nullptr, int P = 1) {
     const wm_dims& c = m->cfg.dims;
     const int T = m->cfg.compute_dtype, KV = m->cfg.kv_dtype;
-    const int B = v.nb;
+    const int B = v.nb * P;          // activation rows of this pass
+    const int qB = P > 1 ? v.nb : 0;  // position-major row mapping on
     const size_t d = c.d_model, ks = dt_size(KV);
     hipStream_t st = v.st;
     const StepCtl* ctl = v.ctl;
@@ -1007,7 +1020,8 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
     float* dq = s->dq.as<float>() + (size_t)v.b0 * d;
     float* dattn = s->dattn.as<float>() + (size_t)v.b0 * d;
     float* dhid = s->dhid.as<float>() + (size_t)v.b0 * c.ffn;
-    launch_dec_embed(m->tok_emb_f.as<float>(), m->dec_pos.as<float>(), s->tok.as<int>() + v.b0, s->pos.as<int>() + v.b0, dx, B, c.d_model, st);
+    launch_dec_embed(m->tok_emb_f.as<float>(), m->dec_pos.as<float>(), P > 1 ? s->tok_rows.as<int>() : s->tok.as<int>() + v.b0,
+                     P > 1 ? s->pos_rows.as<int>() : s->pos.as<int>() + v.b0, dx, B, c.d_model, st);
     for (int l = 0; l < c.n_layers; ++l) {
         DecLayer& w = m->dec[l];
         void* sk = off_bytes(s->self_kv, ((size_t)(2 * l) * self_l + self_b) * ks);
@@ -1030,6 +1044,7 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
             p.kv_batch_stride = (long)((size_t)c.n_text_ctx * d);
             p.d_model = c.d_model;
             p.kv_dtype = KV;
+            p.kv_B = qB;
             p.ctl = ctl;
             dec_linear_dispatch(T, p, st);
         }
@@ -1040,6 +1055,7 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
             a.V = sv;
             a.batch_stride = (long)((size_t)c.n_text_ctx * d);
             a.n_keys = -1;
+            a.q_B = qB;
             a.ctl = ctl;
             a.nsplit = 1;
             a.scale = scale;
@@ -1080,7 +1096,7 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
             p.ldo = c.d_model;
             dec_linear_dispatch(T, p, st);
         }
-        launch_cross_attn(m, s, l, v);
+        launch_cross_attn(m, s, l, v, P);
         // (merging the chunk partials inside the projection's prologue was measured 14 us per layer SLOWER than this
         // 3 us launch: 96 workgroups each re-reading 295 KB of partials)
         launch_attn_combine(s->part_o.as<float>() + (size_t)v.b0 * s->nsplit * d, s->part_ml.as<float>() + (size_t)v.b0 * s->nsplit * c.n_heads * 2,
@@ -1107,14 +1123,14 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
     }
     if (want_logits) {  // final LN + tied-embedding logits (whisper.mojo:156-166), no bias
         DecLinearParams p{};
-        p.x = dx;
+        p.x = dx + (size_t)(P - 1) * v.nb * d;  // rows of the last position
         p.ldx = c.d_model;
         p.ln_g = m->dec_ln_g.as<float>();
         p.ln_b = m->dec_ln_b.as<float>();
         p.W = T == WM_F32 ? m->tok_emb_f.p : m->tok_emb_t.p;
         p.N = c.vocab;
         p.K = c.d_model;
-        p.B = B;
+        p.B = v.nb;
         p.out = full_logits ? s->logits.as<float>() + (size_t)v.b0 * m->Vpad : nullptr;
         p.ldo = m->Vpad;
         p.amax_val = s->amax_val.as<float>() + (size_t)v.b0 * s->npart;
@@ -1236,11 +1252,18 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
         ip.finished = s->finished.as<int>() + v.b0;
         ip.ctl = v.ctl;
         ip.B = v.nb;
+        ip.tok_rows = s->lanes.size() == 1 ? s->tok_rows.as<int>() : nullptr;
+        ip.pos_rows = s->pos_rows.as<int>();
         launch_init_tokens(ip, v.st);
         // prefill (whisper.mojo:195, start_pos=0): the q_len = n_prompt causal block equals n_prompt single-token steps
-        for (int i = 0; i < o->n_prompt; ++i) {
-            launch_set_step(v.ctl, i, 1, s->pos.as<int>() + v.b0, i, s->tok.as<int>() + v.b0, o->prompt[i], v.nb, v.st);
-            decode_core(m, s, v, i == o->n_prompt - 1, false, s->mask_begin.as<float>());
+        static const bool seq_prefill = getenv("WM_SEQ_PREFILL") != nullptr;  // A/B: one pass per prompt position
+        if (!seq_prefill && s->lanes.size() == 1 && o->n_prompt > 1 && o->n_prompt <= wm_state::PREFILL_MAX) {
+            decode_core(m, s, v, true, false, s->mask_begin.as<float>(), o->n_prompt);  // init_tokens filled tok_rows / pos_rows
+        } else {
+            for (int i = 0; i < o->n_prompt; ++i) {
+                launch_set_step(v.ctl, i, 1, s->pos.as<int>() + v.b0, i, s->tok.as<int>() + v.b0, o->prompt[i], v.nb, v.st);
+                decode_core(m, s, v, i == o->n_prompt - 1, false, s->mask_begin.as<float>());
+            }
         }
         launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot), v.st);  // :198-203
         trace_mark(v.st, "state %p lane %d prefill end", (void*)s, v.b0);

@@ -56,6 +56,7 @@ struct DecLinearParams {
     long kv_batch_stride;  // elements between utterances in the cache
     int d_model;
     int kv_dtype;  // WM_F32 / WM_BF16 / WM_F16
+    int kv_B;      // > 0: prompt prefill, rows are position-major (row = t * kv_B + b): row's K/V go to utterance b, cache row len + t
     const StepCtl* ctl;
     // dec_logits only: fused argmax stage 1 — per-utterance best (value, column) of each 128-column workgroup
     float* amax_val;  // [B][amax_stride] or null
@@ -75,6 +76,8 @@ struct AttnDecParams {
     const void* V;
     long batch_stride;
     int n_keys;  // >= 0: fixed key count (cross);  < 0: ctl->len + 1 (self, includes the row just written)
+    int q_B;     // > 0: prompt prefill, query rows are position-major (row = t * q_B + b): K/V of utterance b, self length + t
+    int nq;      // 4 (cross-attention, with q_B): one workgroup per (utterance, chunk) serves the 4 positions; else 0/1
     const StepCtl* ctl;
     int nsplit;
     float scale;
@@ -120,6 +123,8 @@ struct InitTokensParams {
     StepCtl* ctl;
     int B, n_prompt;
     int prompt[16];
+    int* tok_rows;  // non-null: also fill the prefill's position-major token / position rows [n_prompt][B]
+    int* pos_rows;
 };
 void launch_init_tokens(const InitTokensParams& p, hipStream_t st);
 void launch_set_step(StepCtl* ctl, int len, int set_len, int* pos, int pos_value, int* tok, int tok_value, int B,
