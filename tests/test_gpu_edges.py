@@ -156,3 +156,27 @@ def test_eight_slots_in_flight(hip, micro_cfg, micro_weights):
             assert m.transcribe_wait(s) == want[s], (rnd, s)
     with pytest.raises(_lib.WhisperMiError, match="slot"):
         m.transcribe_submit(mels[0], slot=8, **kw)
+
+
+@pytest.mark.parametrize("q_len", [2, 3, 4, 5, 16])
+def test_block_prefill_equals_stepwise(hip, micro_cfg, micro_weights, q_len):
+    """WhisperDecoder.forward on a q_len block (whisper.mojo:195) = the same tokens fed one by one: same logits bit for
+    bit (the block pass runs position-major rows through the same kernels; q_len = 4 also takes the multi-query
+    cross-attention), and the cache ends in the same state (the next step agrees too)."""
+    from whisper_mojo_amd import synth
+    from whisper_mojo_amd.whisper import KVCache
+    m = make_model(micro_cfg, micro_weights, max_batch=3)
+    mels = synth.synth_mels(micro_cfg, 40, 3)
+    r = np.random.default_rng(q_len)
+    toks = r.integers(0, micro_cfg.vocab_size, (3, q_len + 1)).astype(np.int32)
+    ca, cb = KVCache(m, 3), KVCache(m, 3)
+    m.encoder.forward(mels, ca)
+    m.encoder.forward(mels, cb)
+    block = m.decoder.forward(toks[:, :q_len], None, ca, start_pos=0)
+    for i in range(q_len):
+        step = m.decoder.forward(toks[:, i:i + 1], None, cb, start_pos=i)
+    assert np.array_equal(block, step)
+    assert ca.current_len == cb.current_len == q_len
+    na = m.decoder.forward(toks[:, q_len:], None, ca, start_pos=q_len)
+    nb = m.decoder.forward(toks[:, q_len:], None, cb, start_pos=q_len)
+    assert np.array_equal(na, nb)

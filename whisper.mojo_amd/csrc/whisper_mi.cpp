@@ -1185,6 +1185,21 @@ extern "C" int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, i
     hipStream_t st = m->stream;
     const DecView v = whole_batch(m, s);
     std::vector<int32_t> col(B), pos(B);
+    if (q_len > 1 && q_len <= wm_state::PREFILL_MAX) {  // the q_len block of whisper.mojo:195 as ONE position-major pass
+        std::vector<int32_t> trow((size_t)q_len * B), prow((size_t)q_len * B);
+        for (int i = 0; i < q_len; ++i)
+            for (int b = 0; b < B; ++b) {
+                trow[(size_t)i * B + b] = tokens[b * q_len + i];
+                prow[(size_t)i * B + b] = start_pos[b] + i;
+            }
+        HIPCHK(hipMemcpyAsync(s->tok_rows.p, trow.data(), trow.size() * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->pos_rows.p, prow.data(), prow.size() * 4, hipMemcpyHostToDevice, st));
+        launch_set_step(v.ctl, s->host_len, 1, nullptr, 0, nullptr, 0, B, st);
+        decode_core(m, s, v, true, true, nullptr, q_len);
+        HIPCHK(hipStreamSynchronize(st));  // trow / prow go out of scope
+        s->host_len += q_len;
+        q_len = 0;
+    }
     for (int i = 0; i < q_len; ++i) {
         for (int b = 0; b < B; ++b) {
             col[b] = tokens[b * q_len + i];
