@@ -780,6 +780,7 @@ __device__ __forceinline__ void argmax_partials(const float* pv, const int* pi, 
 __global__ __launch_bounds__(1024) void argmax_step_kernel(ArgmaxParams p) {
     const int b = blockIdx.x;
     if (p.ts && b == 0 && threadIdx.x == 0) ts_put(p.ts, p.ts_id, 3);
+    const int pos0 = p.emb_out ? p.pos[b] : 0;  // read before thread 0 advances it (the reductions below synchronise)
     float best;
     int idx;
     if (p.pval)
@@ -800,6 +801,11 @@ __global__ __launch_bounds__(1024) void argmax_step_kernel(ArgmaxParams p) {
                 atomicAdd(&p.ctl->n_finished, 1);
             }
         }
+    }
+    if (p.emb_out) {  // every thread holds idx: next step's embedding row (whisper.mojo:141-149)
+        const float* te = p.emb_tok + (size_t)idx * p.d;
+        const float* pe = p.emb_pos + (size_t)min(pos0 + (p.advance ? 1 : 0), p.max_pos) * p.d;
+        for (int j = threadIdx.x; j < p.d; j += blockDim.x) p.emb_out[(size_t)b * p.d + j] = te[j] + pe[j];
     }
 }
 void launch_argmax_step(const ArgmaxParams& p, hipStream_t st) {

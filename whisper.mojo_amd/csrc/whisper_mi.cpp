@@ -1005,7 +1005,7 @@ static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v,
 // self-attention of position t sees keys 0..len+t (the causal mask of layers.mojo:309-318), logits only for the last
 // position.  Every row's arithmetic is what the single-position pass does for it, so the ids are the same bit for bit.
 static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_logits, bool full_logits = false,
-                        const float* mask = nullptr, int P = 1) {
+                        const float* mask = nullptr, int P = 1, bool embed = true) {
     const wm_dims& c = m->cfg.dims;
     const int T = m->cfg.compute_dtype, KV = m->cfg.kv_dtype;
     const int B = v.nb * P;          // activation rows of this pass
@@ -1020,7 +1020,8 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
     float* dq = s->dq.as<float>() + (size_t)v.b0 * d;
     float* dattn = s->dattn.as<float>() + (size_t)v.b0 * d;
     float* dhid = s->dhid.as<float>() + (size_t)v.b0 * c.ffn;
-    launch_dec_embed(m->tok_emb_f.as<float>(), m->dec_pos.as<float>(), P > 1 ? s->tok_rows.as<int>() : s->tok.as<int>() + v.b0,
+    if (embed)  // (the greedy loop's steps get their input row from the previous step's argmax launch instead)
+        launch_dec_embed(m->tok_emb_f.as<float>(), m->dec_pos.as<float>(), P > 1 ? s->tok_rows.as<int>() : s->tok.as<int>() + v.b0,
                      P > 1 ? s->pos_rows.as<int>() : s->pos.as<int>() + v.b0, dx, B, c.d_model, st);
     for (int l = 0; l < c.n_layers; ++l) {
         DecLayer& w = m->dec[l];
@@ -1144,7 +1145,7 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
 }
 
 static ArgmaxParams argmax_params(wm_model* m, wm_state* s, const DecView& v, bool record, int eot, int ignore_eot,
-                                  bool advance = false) {
+                                  bool advance = false, bool embed_next = false) {
     ArgmaxParams a{};
     a.logits = s->logits.as<float>() + (size_t)v.b0 * m->Vpad;
     a.pval = s->amax_val.as<float>() + (size_t)v.b0 * s->npart;
@@ -1165,6 +1166,13 @@ static ArgmaxParams argmax_params(wm_model* m, wm_state* s, const DecView& v, bo
     a.pos = s->pos.as<int>() + v.b0;
     a.ts = (long long*)m->ts_buf.p;
     a.ts_id = s->trace_id;
+    if (embed_next) {
+        a.emb_tok = m->tok_emb_f.as<float>();
+        a.emb_pos = m->dec_pos.as<float>();
+        a.emb_out = s->dx.as<float>() + (size_t)v.b0 * m->cfg.dims.d_model;
+        a.d = m->cfg.dims.d_model;
+        a.max_pos = m->cfg.dims.n_text_ctx - 1;
+    }
     return a;
 }
 
@@ -1284,6 +1292,9 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
         trace_mark(v.st, "state %p lane %d prefill end", (void*)s, v.b0);
         // incremental steps: start_pos = current_len - 1 (reference, :217) or current_len (HF)
         launch_set_step(v.ctl, o->n_prompt, 1, s->pos.as<int>() + v.b0, first_pos, nullptr, 0, v.nb, v.st);
+        // input row of the first loop step; every later step's row is written by the preceding step's argmax launch
+        launch_dec_embed(m->tok_emb_f.as<float>(), m->dec_pos.as<float>(), s->tok.as<int>() + v.b0, s->pos.as<int>() + v.b0,
+                         s->dx.as<float>() + (size_t)v.b0 * m->cfg.dims.d_model, v.nb, m->cfg.dims.d_model, v.st);
         // steady state: one captured graph per lane = [37 decode-step launches + argmax/bookkeeping]; every per-step
         // quantity (token, position, cache length) lives in HBM, so the same graph is replayed for every token
         if (!no_graph && (recapture || !ln.graph[0])) {
@@ -1293,8 +1304,8 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
             }
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(v.st, hipStreamCaptureModeThreadLocal));
-            decode_core(m, s, v, true, false, s->mask_steady.as<float>());
-            launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, true), v.st);
+            decode_core(m, s, v, true, false, s->mask_steady.as<float>(), 1, false);
+            launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, true, true), v.st);
             HIPCHK(hipStreamEndCapture(v.st, &g));
             hipError_t ge = hipSuccess;
             for (int k = 0; k < wm_state::Lane::NEXEC && ge == hipSuccess; ++k) ge = hipGraphInstantiate(&ln.graph[k], g, nullptr, nullptr, 0);
@@ -1336,8 +1347,8 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
                 }
             } else {
                 const DecView v{ln.b0, ln.nb, ln.st, ln.ctl};
-                decode_core(m, s, v, true, false, s->mask_steady.as<float>());
-                launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, true), v.st);
+                decode_core(m, s, v, true, false, s->mask_steady.as<float>(), 1, false);
+                launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, true, true), v.st);
             }
         }
     }

@@ -113,6 +113,12 @@ struct ArgmaxParams {
     int* pos;
     long long* ts;  // developer timeline (null = off)
     int ts_id;
+    // non-null: also write the NEXT step's input row x[b] = tok_emb[chosen id] + pos_emb[pos[b] (+1 when advancing)] — the
+    // embedding launch of the following step folded into this one
+    const float* emb_tok;
+    const float* emb_pos;
+    float* emb_out;
+    int d, max_pos;
 };
 void launch_argmax_step(const ArgmaxParams& p, hipStream_t st);
 struct InitTokensParams {
