@@ -645,7 +645,13 @@ template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStrea
         else
             hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 4>), grid, block, 0, st, q);
     } else {
-        hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, false, 2>), grid, block, 0, st, q);
+        // self-attention: 4 rows per lane per iteration (measured per 64-clip pass alone: U = 1 / 2 34.6 ms, U = 4 34.3 ms — the
+        // serial iteration count matters as the cache grows to 104 rows).  WM_SELF_U=2 for A/B.
+        static const int u_self = getenv("WM_SELF_U") ? atoi(getenv("WM_SELF_U")) : 4;
+        if (u_self == 2)
+            hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, false, 2>), grid, block, 0, st, q);
+        else
+            hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, false, 4>), grid, block, 0, st, q);
     }
 }
 template void launch_attn_decode<float>(const AttnDecParams&, hipStream_t);
