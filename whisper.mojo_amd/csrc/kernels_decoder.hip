@@ -626,6 +626,8 @@ template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStrea
     // fp32 K/V rows are twice as wide (96-128 lanes per row): the latency-bound self-attention takes 512 threads so a
     // lane's serial key loop stays short (61 keys: 16 -> 7 iterations)
     q.rps = ((sizeof(TKV) == 4 && p.n_keys < 0) ? 512 : 256) / LPR;
+    static const int thr_self = getenv("WM_SELF_THREADS") ? atoi(getenv("WM_SELF_THREADS")) : 0;  // A/B: self-attention block size
+    if (thr_self && p.n_keys < 0) q.rps = std::max(1, std::min(512, thr_self) / LPR);
     static const int thr_cross = getenv("WM_ATTN_THREADS") ? atoi(getenv("WM_ATTN_THREADS")) : 0;  // A/B: cross-attention block size
     if (thr_cross && p.n_keys >= 0) q.rps = std::max(1, std::min(512, thr_cross) / LPR);
     // block rounded up to whole waves: the spare lanes take no rows (rslot >= RPS) but stay in the DPP groups
