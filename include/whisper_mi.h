@@ -108,8 +108,8 @@ int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, int q_len, c
 int wm_transcribe(wm_model* m, const float* mel, int mel_on_device, int B, const wm_decode_opts* opts,
                   int32_t* tokens_out, int32_t* n_tokens);
 
-/* Pipelined form for back-to-back batches (serving / bench): wm_transcribe_submit enqueues the encoder (model stream) and
- * the whole greedy loop (the slot's decode stream) and returns immediately; wm_transcribe_wait blocks until that slot's
+/* Pipelined form for back-to-back batches (serving / bench): wm_transcribe_submit enqueues the encoder, the
+ * prompt prefill and the whole greedy loop on the slot's own HIP stream and returns immediately; wm_transcribe_wait blocks until that slot's
  * ids are ready and copies them out (same layout as wm_transcribe).  Eight slots (0..7): submitting batch i+1 before
  * waiting for batch i overlaps its MFMA-bound encoder with batch i's latency/HBM-bound decode; four passes in flight is
  * the measured optimum (the chip runs four hardware queues at a time, and ROCm must be allowed that many per-process

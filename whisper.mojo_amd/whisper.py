@@ -194,7 +194,7 @@ class Whisper:
 
     def transcribe_submit(self, mel, slot: int = 0, prompt: Sequence[int] = PROMPT, eot: int = EOT, max_loop: int = MAX_LOOP,
                           ignore_eot: bool = False):
-        """Pipelined form (wm_transcribe_submit): enqueue encoder + greedy loop for this batch on pipeline slot 0/1 and
+        """Pipelined form (wm_transcribe_submit): enqueue encoder + greedy loop for this batch on pipeline slot 0..7 and
         return at once; `transcribe_wait(slot)` collects the ids.  Submitting batch i+1 before waiting for batch i lets
         its encoder overlap batch i's decode."""
         if self._h is None:
