@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--no-x4", action="store_true", help="skip the four-chains-in-flight decode step timing (profiler runs: keeps every launch of the dominant kernel alone on the chip)")
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after another")
     ap.add_argument("--pipeline", type=int, default=4, choices=[1, 2, 3, 4, 5, 6, 7, 8], help="steps in flight (library pipeline slots)")
+    ap.add_argument("--dump-ids", default="", help="rank 0 writes the gathered ids of the last timed step to this .npy file (tests)")
     args = ap.parse_args()
 
     import torch
@@ -196,6 +197,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     assert out is not None and len(out) == total and all(len(o) == stride for o in out)
+    if args.dump_ids and rank == 0:
+        np.save(args.dump_ids, np.asarray(out, np.int32))
 
     log(f"timed region done: {dt:.3f} s")
     # the same K steps strictly one after another (no overlap between steps), for reference

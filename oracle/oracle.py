@@ -23,11 +23,24 @@ class WmDims(C.Structure):
 
 
 def build(force: bool = False) -> str:
+    """make -C oracle when the sources' CONTENT changed (sha256 kept in a .stamp file: mtimes do not survive the snapshot
+    copy to the GPU box, and an mtime rule would recompile there)."""
+    import hashlib
     srcs = [os.path.join(_HERE, f) for f in ("whisper_oracle.c", "oracle_synth.c", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "wm_synth.h"))
-    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs if os.path.exists(s))
-    if force or stale:
-        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    h = hashlib.sha256()
+    for p in srcs:
+        with open(p, "rb") as f:
+            h.update(os.path.basename(p).encode() + b"\0" + f.read())
+    digest, stamp = h.hexdigest(), _SO + ".stamp"
+    try:
+        fresh = os.path.exists(_SO) and open(stamp).read().strip() == digest
+    except OSError:
+        fresh = False
+    if force or not fresh:
+        subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
+        with open(stamp, "w") as f:
+            f.write(digest + "\n")
     return _SO
 
 

@@ -8,7 +8,8 @@ import os
 from .config import WmDims
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libwhispermi.so")
+# WM_USE_DEV_LIB=1 (developer tools only) selects the -DWM_DEV build with the A/B switches and debug chains
+LIB_PATH = os.path.join(_HERE, "csrc", "libwhispermi_dev.so" if os.environ.get("WM_USE_DEV_LIB") else "libwhispermi.so")
 
 # every symbol include/whisper_mi.h declares (tests/test_cabi_symbols.py checks the .so exports all of them)
 SYMBOLS = [

@@ -7,6 +7,7 @@
 // position add (whisper.mojo:141-149); argmax (whisper_tensor.mojo:431-439).
 #include "wm_kernels.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -209,14 +210,21 @@ template <typename TW, int KPW> static void launch_dec_linear_t(const DecLinearP
     }
 }
 // K % 32 == 0 and (K/32) must factor as NW * KPW with NW <= 16, KPW <= 4 (true for every K = 128·j, j <= 16).
+static int dec_linear_waves(int K) {
+    if (K <= 0 || (K & 31)) return 0;
+    const int ksteps = K >> 5;
+    for (int c = 16; c >= 1; --c)
+        if (ksteps % c == 0 && ksteps / c <= 4) return c;
+    return 0;
+}
+bool dec_linear_supports_k(int K) { return dec_linear_waves(K) > 0; }
 template <typename TW> void launch_dec_linear(const DecLinearParams& p, hipStream_t st) {
     const int ksteps = p.K >> 5;
-    int nw = 1;
-    for (int c = 16; c >= 1; --c)
-        if (ksteps % c == 0 && ksteps / c <= 4) {
-            nw = c;
-            break;
-        }
+    const int nw = dec_linear_waves(p.K);
+    if (nw == 0) {  // never reached through the C-ABI (check_cfg / wm_op_matmul_nt pad K): refuse rather than drop k-steps
+        fprintf(stderr, "[whispermi] dec_linear: K = %d cannot be split over the waves of a workgroup — launch skipped\n", p.K);
+        return;
+    }
     switch (ksteps / nw) {
         case 1: return launch_dec_linear_t<TW, 1>(p, nw, st);
         case 2: return launch_dec_linear_t<TW, 2>(p, nw, st);
@@ -439,12 +447,7 @@ int dec_logits_parts(int N) {
 }
 template <typename TW, int KD, int NRB> static void launch_dec_logits_t(const DecLinearParams& p, hipStream_t st) {
     const size_t lds = (size_t)NRB * 16 * (KD * 128 + (sizeof(TW) == 2 ? 80 : 16 / sizeof(TW))) * sizeof(TW);
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_logits_kernel<TW, KD, NRB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    if (lds > 48 * 1024) (void)ensure_dyn_lds(&dec_logits_kernel<TW, KD, NRB>, (int)lds);  // a failure surfaces through hipGetLastError
     const int ct = dec_logits_tiles_per_wg(p.N);
     dim3 grid(dec_logits_parts(p.N), (p.B + NRB * 16 - 1) / (NRB * 16));
     hipLaunchKernelGGL((dec_logits_kernel<TW, KD, NRB>), grid, dim3(512), lds, st, p, ct);
@@ -626,14 +629,14 @@ template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStrea
     // fp32 K/V rows are twice as wide (96-128 lanes per row): the latency-bound self-attention takes 512 threads so a
     // lane's serial key loop stays short (61 keys: 16 -> 7 iterations)
     q.rps = ((sizeof(TKV) == 4 && p.n_keys < 0) ? 512 : 256) / LPR;
-    static const int thr_self = getenv("WM_SELF_THREADS") ? atoi(getenv("WM_SELF_THREADS")) : 0;  // A/B: self-attention block size
+    static const int thr_self = wm_env("WM_SELF_THREADS") ? atoi(wm_env("WM_SELF_THREADS")) : 0;  // A/B: self-attention block size
     if (thr_self && p.n_keys < 0) q.rps = std::max(1, std::min(512, thr_self) / LPR);
-    static const int thr_cross = getenv("WM_ATTN_THREADS") ? atoi(getenv("WM_ATTN_THREADS")) : 0;  // A/B: cross-attention block size
+    static const int thr_cross = wm_env("WM_ATTN_THREADS") ? atoi(wm_env("WM_ATTN_THREADS")) : 0;  // A/B: cross-attention block size
     if (thr_cross && p.n_keys >= 0) q.rps = std::max(1, std::min(512, thr_cross) / LPR);
     // block rounded up to whole waves: the spare lanes take no rows (rslot >= RPS) but stay in the DPP groups
     const dim3 grid(p.nsplit, p.B), block((q.rps * LPR + 63) / 64 * 64);
-    static const bool nt_off = getenv("WM_NO_NT") != nullptr;
-    static const int u_cross = getenv("WM_ATTN_U") ? atoi(getenv("WM_ATTN_U")) : 4;
+    static const bool nt_off = wm_env("WM_NO_NT") != nullptr;
+    static const int u_cross = wm_env("WM_ATTN_U") ? atoi(wm_env("WM_ATTN_U")) : 4;
     if (p.n_keys >= 0 && p.nq == 4) {  // prompt prefill, four positions per utterance from one K/V sweep (q_B = utterances)
         const dim3 grid4(p.nsplit, p.q_B);
         hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 4, 4>), grid4, block, 0, st, q);  // U = 4 as in the step kernel: same arithmetic per query
@@ -649,7 +652,7 @@ template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStrea
     } else {
         // self-attention: 4 rows per lane per iteration (measured per 64-clip pass alone: U = 1 / 2 34.6 ms, U = 4 34.3 ms — the
         // serial iteration count matters as the cache grows to 104 rows).  WM_SELF_U=2 for A/B.
-        static const int u_self = getenv("WM_SELF_U") ? atoi(getenv("WM_SELF_U")) : 4;
+        static const int u_self = wm_env("WM_SELF_U") ? atoi(wm_env("WM_SELF_U")) : 4;
         if (u_self == 2)
             hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, false, 2>), grid, block, 0, st, q);
         else
@@ -795,6 +798,10 @@ __global__ __launch_bounds__(1024) void argmax_step_kernel(ArgmaxParams p) {
         argmax_partials(p.pval + (size_t)b * p.npart, p.pidx + (size_t)b * p.npart, p.npart, best, idx);
     else
         argmax_block(p.logits + (size_t)b * p.ldl, p.V, best, idx);
+    // every candidate NaN / -inf (16-bit overflow, bad weights, a mask over the whole vocabulary): no comparison succeeded and
+    // idx is still the sentinel — it must not become an embedding row index.  The reference's scan (whisper_tensor.mojo:431-439:
+    // start at t[0], strict '>') returns index 0 in exactly these cases, and so does this.
+    if ((unsigned)idx >= (unsigned)p.V) idx = 0;
     if (threadIdx.x == 0) {
         p.next[b] = idx;
         if (p.advance) {  // current_len += 1 (layers.mojo:143), position += 1: nothing else in this launch reads them
@@ -823,6 +830,7 @@ __global__ __launch_bounds__(1024) void argmax_plain_kernel(const float* t, int 
     float best;
     int i;
     argmax_block(t, n, best, i);
+    if ((unsigned)i >= (unsigned)n) i = 0;  // all-NaN / all -inf input: the reference's scan (whisper_tensor.mojo:431-439) returns 0
     if (threadIdx.x == 0) *idx = i;
 }
 void launch_argmax_plain(const float* t, int n, int* idx, hipStream_t st) {

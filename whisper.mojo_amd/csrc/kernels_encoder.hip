@@ -434,29 +434,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_rowpanel_kernel(GemmParams p, 
 }
 template <typename T, typename TO, int KS> static void launch_rowpanel(const GemmParams& p, hipStream_t st) {
     const int n_units = ((p.M + 127) / 128) * (p.N / 128);
-    static const int grid_max = getenv("WM_RP_GRID") ? atoi(getenv("WM_RP_GRID")) : 512;  // two 64-KB-ring workgroups per CU
+    static const int grid_max = wm_env("WM_RP_GRID") ? atoi(wm_env("WM_RP_GRID")) : 512;  // two 64-KB-ring workgroups per CU
     const int grid = std::min(n_units, grid_max);
     const size_t lds = (size_t)4 * 128 * 64 * sizeof(T) + (size_t)p.N * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_rowpanel_kernel<T, TO, KS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_set = true;
-    }
+    (void)ensure_dyn_lds(&gemm_nt_rowpanel_kernel<T, TO, KS>, 80 * 1024);  // per device; a failure surfaces through hipGetLastError
     hipLaunchKernelGGL((gemm_nt_rowpanel_kernel<T, TO, KS>), dim3(grid), dim3(256), lds, st, p, n_units);
 }
 
 template <typename T, typename TO> void launch_gemm_nt(const GemmParams& p, int batch, hipStream_t st) {
     dim3 grid(p.N / 128, (p.M + 127) / 128, batch);
-    static const bool no_lds = getenv("WM_GEMM_DIRECT") != nullptr;
+    static const bool no_lds = wm_env("WM_GEMM_DIRECT") != nullptr;
     if constexpr (sizeof(T) == 2) {
         // A-stationary row-panel kernel: plain [M,K]x[N,K] (no conv batching), K = 384 (K = 512 needs 128 A registers: spills), no addends, N <= 3072
-        static const bool no_rp = getenv("WM_GEMM_NO_ROWPANEL") != nullptr;
+        static const bool no_rp = wm_env("WM_GEMM_NO_ROWPANEL") != nullptr;
         if (!no_rp && !no_lds && batch == 1 && !p.residual && !p.pos && p.N <= 3072 && (p.group_n == 0 || p.group_n % 128 == 0)) {
             if (p.K == 384) return launch_rowpanel<T, TO, 12>(p, st);
         }
         if (!no_lds && (p.K & 63) == 0) {
-            static const bool no_remap = getenv("WM_GEMM_NOXCD") != nullptr;
+            static const bool no_remap = wm_env("WM_GEMM_NOXCD") != nullptr;
             GemmParams q = p;
             q.xcd_remap = !no_remap;
             hipLaunchKernelGGL((gemm_nt_lds_kernel<T, TO>), grid, dim3(256), 0, st, q);
@@ -850,10 +845,10 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_enc_v2_kernel(const T* __r
 
 template <typename T>
 void launch_flash_attn_enc(const void* qkv, void* out, int B, int H, int n_ctx, float scale, hipStream_t st) {
-    static const bool v1 = getenv("WM_ATTN_V1") != nullptr;
+    static const bool v1 = wm_env("WM_ATTN_V1") != nullptr;
     // measured (tiny, 8 utterances per pass, encoder ms per 64 clips): 8 waves x 1 q-block 9.73 | 4x1 9.75 | 4x2 10.13 | 8x2 10.31
-    static const int var = getenv("WM_ATTN_VAR") ? atoi(getenv("WM_ATTN_VAR")) : 1;
-    static const bool no_xcd = getenv("WM_ATTN_NOXCD") != nullptr;
+    static const int var = wm_env("WM_ATTN_VAR") ? atoi(wm_env("WM_ATTN_VAR")) : 1;
+    static const bool no_xcd = wm_env("WM_ATTN_NOXCD") != nullptr;
     if constexpr (sizeof(T) == 2) {
         if (!v1) {
             const int remap = (!no_xcd && (B * H) % 8 == 0) ? 1 : 0;

@@ -15,7 +15,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "wm_kernels.h"
@@ -54,7 +56,7 @@ struct TraceMark {
 };
 static std::vector<TraceMark> g_trace;
 static bool trace_events_on() {
-    static const bool on = getenv("WM_TRACE_EVENTS") != nullptr;
+    static const bool on = wm_env("WM_TRACE_EVENTS") != nullptr;
     return on;
 }
 static void trace_mark(hipStream_t st, const char* fmt, ...) {
@@ -143,6 +145,15 @@ static int upload(DevBuf& b, const float* h, size_t n, int dt) {
     return 0;
 }
 
+// Every live wm_state: a handle that is not in here (already freed — e.g. by wm_model_free, which owns the states created
+// on it — or never valid) is rejected instead of dereferenced.
+static std::mutex g_states_mu;
+static std::unordered_set<const void*> g_live_states;
+static bool state_is_live(const void* s) {
+    std::lock_guard<std::mutex> lk(g_states_mu);
+    return s && g_live_states.count(s) != 0;
+}
+
 struct EncLayer {
     DevBuf qkv_w, qkv_b, o_w, o_b, ln1_g, ln1_b, fc1_w, fc1_b, fc2_w, fc2_b, ln2_g, ln2_b;
 };
@@ -178,6 +189,7 @@ struct wm_model {
     static const int NSLOT = 8;
     wm_state* cached = nullptr;           // slot 0: the state behind wm_transcribe / wm_transcribe_submit(slot 0)
     wm_state* slots[NSLOT - 1] = {};  // slots 1..7: further pipeline stages (wm_transcribe_submit)
+    std::unordered_set<wm_state*> states;  // every state created on this model (wm_state_new), freed with it
 };
 
 struct wm_state {
@@ -265,6 +277,12 @@ static int check_cfg(const wm_config* c) {
         return fail(WM_E_ARG, "d_model must equal n_heads*64 (got %d, %d)", d.d_model, d.n_heads);
     if (d.n_heads > 8) return fail(WM_E_ARG, "n_heads > 8 not supported");
     if (d.d_model % 128 || d.ffn % 128) return fail(WM_E_ARG, "d_model and ffn must be multiples of 128");
+    // what the decode kernels are instantiated for: the logits kernel keeps d_model/128 in {1, 3, 4} k-panels
+    // (kernels_decoder.hip launch_dec_logits), the skinny linears split K/32 k-steps over <= 16 waves x <= 4 steps
+    if (d.d_model != 128 && d.d_model != 384 && d.d_model != 512)
+        return fail(WM_E_ARG, "d_model %d not supported (128, 384 or 512)", d.d_model);
+    if (!dec_linear_supports_k(d.d_model) || !dec_linear_supports_k(d.ffn))
+        return fail(WM_E_ARG, "ffn %d not supported (ffn/32 must split into <= 16 waves x <= 4 k-steps, ffn <= 2048)", d.ffn);
     if ((d.n_layers * 2 * d.d_model) % 128) return fail(WM_E_ARG, "n_layers*2*d_model must be a multiple of 128");
     if (d.n_text_ctx > 512) return fail(WM_E_ARG, "n_text_ctx > 512 not supported");
     if (d.n_mels <= 0 || d.n_audio_ctx <= 0 || d.vocab <= 0 || d.n_layers <= 0) return fail(WM_E_ARG, "bad dims");
@@ -315,7 +333,7 @@ extern "C" void wm_model_free(wm_model* m) {
     if (m && trace_events_on()) {
         trace_dump();
         {
-            const char* path = getenv("WM_TRACE_EVENTS");
+            const char* path = wm_env("WM_TRACE_EVENTS");
             if (m->ts_buf.p && path) {
                 std::vector<long long> h((2u << 20) + 1);
                 if (hipMemcpy(h.data(), m->ts_buf.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -330,9 +348,9 @@ extern "C" void wm_model_free(wm_model* m) {
     }
     if (!m) return;
     (void)hipSetDevice(m->device);
-    if (m->cached) wm_state_free(m->cached);
-    for (auto& sl : m->slots)
-        if (sl) wm_state_free(sl);
+    // the model owns every state created on it (pipeline slots and the caller's KVCaches): a handle the caller still holds
+    // becomes stale — wm_state_free / wm_decode_step on it is a checked no-op / error, not a use after free
+    while (!m->states.empty()) wm_state_free(*m->states.begin());
     {
         DevBuf* fb[] = {&m->fe.window, &m->fe.dft, &m->fe.fb, &m->fe.band, &m->fe.pcm, &m->fe.lens, &m->fe.frames, &m->fe.spec, &m->fe.logtmp, &m->fe.mel};
         for (DevBuf* b : fb) b->release();
@@ -442,7 +460,7 @@ static int model_build(wm_model* m, const float* w) {
     WMCHK(upload(m->dec_ln_b, r.take(d), d, WM_F32));
     WMCHK(upload(m->cross_kv_w, ckv.data(), ckv.size(), T));
     WMCHK(upload(m->cross_kv_b, ckvb.data(), ckvb.size(), WM_F32));
-    if (trace_events_on() && strchr(getenv("WM_TRACE_EVENTS"), '/')) WMCHK(m->ts_buf.alloc(((2u << 20) + 1) * 8, true));
+    if (trace_events_on() && strchr(wm_env("WM_TRACE_EVENTS"), '/')) WMCHK(m->ts_buf.alloc(((2u << 20) + 1) * 8, true));
     if (r.off != wm_synth_count(&c)) return fail(WM_E_SIZE, "internal: consumed %zu floats, expected %zu", r.off, wm_synth_count(&c));
     return 0;
 }
@@ -461,7 +479,7 @@ extern "C" int wm_model_load_memory(const float* weights, size_t n_floats, const
     wm_model* m = new wm_model();
     m->cfg = *cfg;
     m->device = device;
-    if (const char* e = getenv("WM_ENC_CHUNK")) m->enc_chunk = std::max(1, atoi(e));
+    if (const char* e = wm_env("WM_ENC_CHUNK")) m->enc_chunk = std::max(1, atoi(e));
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete m;
@@ -627,7 +645,20 @@ extern "C" int wm_model_load(const char* path, const wm_config* cfg, int device,
 // ---- state ---------------------------------------------------------------------------------------------------
 extern "C" void wm_state_free(wm_state* s) {
     if (!s) return;
+    {
+        std::lock_guard<std::mutex> lk(g_states_mu);
+        if (!g_live_states.erase(s)) return;  // stale handle: its model was freed (and took the state with it)
+    }
+    s->m->states.erase(s);
+    if (s->m->cached == s) s->m->cached = nullptr;
+    for (auto& sl : s->m->slots)
+        if (sl == s) sl = nullptr;
     (void)hipSetDevice(s->m->device);
+    // nothing of this state may still be running when its graphs, streams and arenas go away (a submitted pass that was
+    // never waited for, or the model stream's last wm_decode_step)
+    for (auto& ln : s->lanes)
+        if (ln.st) (void)hipStreamSynchronize(ln.st);
+    if (s->m->stream) (void)hipStreamSynchronize(s->m->stream);
     for (auto& ln : s->lanes) {
         for (auto& g : ln.graph)
             if (g) (void)hipGraphExecDestroy(g);
@@ -655,6 +686,11 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
     wm_state* s = new wm_state();
     s->m = m;
     s->B = B;
+    {
+        std::lock_guard<std::mutex> lk(g_states_mu);
+        g_live_states.insert(s);
+    }
+    m->states.insert(s);
     s->Bc = std::min(B, m->enc_chunk);
     // key chunks per utterance for the cross-attention kernel: a function of the MODEL's max_batch, never of this call's
     // B, so that an utterance's result does not depend on how it was batched (bitwise batch invariance within a model).
@@ -666,7 +702,7 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
         int ns = (1024 + m->cfg.max_batch - 1) / m->cfg.max_batch;
         ns = std::max(12, std::min(48, ns));
         ns = std::max(min_split, std::min(ns, (int)((T + 31) / 32)));
-        if (const char* e = getenv("WM_NSPLIT")) ns = std::max(min_split, std::min(64, atoi(e)));
+        if (const char* e = wm_env("WM_NSPLIT")) ns = std::max(min_split, std::min(64, atoi(e)));
         s->nsplit = ns;
     }
     s->out_stride = OUT_STRIDE_MAX;
@@ -720,7 +756,7 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
         // measured on MI355X (round 1): 2 lanes 49.1 ms vs 1 lane 47.4 ms per 64-clip pass — kernel boundaries of one
         // queue also stall the other queue's kernels, so extra lanes stay opt-in (WM_DEC_LANES)
         int nl = 1;
-        if (const char* e = getenv("WM_DEC_LANES")) nl = std::max(1, std::min(4, atoi(e)));
+        if (const char* e = wm_env("WM_DEC_LANES")) nl = std::max(1, std::min(4, atoi(e)));
         nl = std::min(nl, (B + 15) / 16);
         s->lanes.resize(nl);
         const int per = ((B + nl - 1) / nl + 15) / 16 * 16;  // whole MFMA row blocks per lane
@@ -735,7 +771,7 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
             // throughput work.  WM_DEC_PRIORITY=1 puts the lane streams on the highest HIP stream priority.
             int lo_p = 0, hi_p = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
-            static const bool prio = getenv("WM_DEC_PRIORITY") != nullptr;
+            static const bool prio = wm_env("WM_DEC_PRIORITY") != nullptr;
             hipError_t e = prio ? hipStreamCreateWithPriority(&ln.st, hipStreamNonBlocking, hi_p)
                                 : hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.done, hipEventDisableTiming);
@@ -761,7 +797,7 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
 }
 
 extern "C" int wm_state_reset(wm_state* s) {
-    if (!s) return fail(WM_E_ARG, "null state");
+    if (!state_is_live(s)) return fail(WM_E_ARG, "null or stale state handle");
     HIPCHK(hipSetDevice(s->m->device));
     hipStream_t st = s->m->stream;
     HIPCHK(hipMemsetAsync(s->ctl.p, 0, s->ctl.bytes, st));
@@ -771,7 +807,7 @@ extern "C" int wm_state_reset(wm_state* s) {
     s->host_len = 0;
     return 0;
 }
-extern "C" int wm_state_len(const wm_state* s) { return s ? s->host_len : -1; }
+extern "C" int wm_state_len(const wm_state* s) { return state_is_live(s) ? s->host_len : -1; }
 
 // ---- encoder: whisper.mojo:71-99 ------------------------------------------------------------------------------------
 static void* off_bytes(const DevBuf& b, size_t bytes) { return (char*)b.p + bytes; }
@@ -913,6 +949,7 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
 
 static int check_state(wm_model* m, wm_state* s, int B) {
     if (!m || !s) return fail(WM_E_ARG, "null handle");
+    if (!state_is_live(s)) return fail(WM_E_ARG, "stale state handle (its model was freed or reloaded)");
     if (s->m != m) return fail(WM_E_ARG, "state belongs to another model");
     if (B != s->B) return fail(WM_E_ARG, "B=%d but the state was created for %d", B, s->B);
     return 0;
@@ -991,7 +1028,7 @@ static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v,
     a.d = c.d_model;
     a.B = v.nb * P;
     a.q_B = P > 1 ? v.nb : 0;
-    static const bool no_mq = getenv("WM_NO_MQ_PREFILL") != nullptr;
+    static const bool no_mq = wm_env("WM_NO_MQ_PREFILL") != nullptr;
     a.nq = (P == 4 && !no_mq) ? 4 : 0;  // the reference's 4-token prompt: one K/V sweep for the four positions
     a.ts = (long long*)m->ts_buf.p;
     a.ts_id = s->trace_id;
@@ -1204,6 +1241,7 @@ extern "C" int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, i
         HIPCHK(hipMemcpyAsync(s->pos_rows.p, prow.data(), prow.size() * 4, hipMemcpyHostToDevice, st));
         launch_set_step(v.ctl, s->host_len, 1, nullptr, 0, nullptr, 0, B, st);
         decode_core(m, s, v, true, true, nullptr, q_len);
+        HIPCHK(hipGetLastError());         // a launch that failed (bad configuration, LDS attribute) is reported here
         HIPCHK(hipStreamSynchronize(st));  // trow / prow go out of scope
         s->host_len += q_len;
         q_len = 0;
@@ -1217,6 +1255,7 @@ extern "C" int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, i
         HIPCHK(hipMemcpyAsync(s->pos.p, pos.data(), B * 4, hipMemcpyHostToDevice, st));
         launch_set_step(v.ctl, s->host_len, 1, nullptr, 0, nullptr, 0, B, st);
         decode_core(m, s, v, i == q_len - 1, true);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));  // col/pos are reused next iteration
         s->host_len += 1;
     }
@@ -1239,9 +1278,9 @@ extern "C" int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, i
 static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, bool allow_poll) {
     const int B = s->B;
     HIPCHK(hipEventRecord(s->enc_done, s->enc_stream ? s->enc_stream : m->stream));  // encoder + cross K/V of this state
-    static const bool trace_phase = getenv("WM_TRACE_HOST") != nullptr;
+    static const bool trace_phase = wm_env("WM_TRACE_HOST") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
-    static const bool no_graph = getenv("WM_NO_GRAPH") != nullptr;
+    static const bool no_graph = wm_env("WM_NO_GRAPH") != nullptr;
     const bool recapture = !s->graphs_valid || s->graph_eot != o->eot || s->graph_ignore != o->ignore_eot;
     const int first_pos = o->pos_mode == WM_POS_REF ? o->n_prompt - 1 : o->n_prompt;
     // logit masks (§8f rank 4): rebuilt only when the id lists change; always passed (all-zero = the reference's raw argmax)
@@ -1279,7 +1318,7 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
         ip.pos_rows = s->pos_rows.as<int>();
         launch_init_tokens(ip, v.st);
         // prefill (whisper.mojo:195, start_pos=0): the q_len = n_prompt causal block equals n_prompt single-token steps
-        static const bool seq_prefill = getenv("WM_SEQ_PREFILL") != nullptr;  // A/B: one pass per prompt position
+        static const bool seq_prefill = wm_env("WM_SEQ_PREFILL") != nullptr;  // A/B: one pass per prompt position
         if (!seq_prefill && s->lanes.size() == 1 && o->n_prompt > 1 && o->n_prompt <= wm_state::PREFILL_MAX) {
             decode_core(m, s, v, true, false, s->mask_begin.as<float>(), o->n_prompt);  // init_tokens filled tok_rows / pos_rows
         } else {
@@ -1386,19 +1425,21 @@ static int check_opts(wm_model* m, const wm_decode_opts* o, int B) {
 static int submit_on(wm_model* m, wm_state** slot, const float* mel, int mel_on_device, int B, const wm_decode_opts* o, bool allow_poll) {
     const wm_dims& c = m->cfg.dims;
     HIPCHK(hipSetDevice(m->device));
+    // a pass that was submitted and not yet waited for owns the slot's state: refuse BEFORE touching it (re-creating the
+    // state for another batch size would destroy graphs, streams and arenas under its running kernels)
+    if (*slot && (*slot)->pending) return fail(WM_E_STATE, "this slot still holds a pass that was not waited for");
     if (!*slot || (*slot)->B != B) {
         if (*slot) wm_state_free(*slot);
         *slot = nullptr;
         WMCHK(wm_state_new(m, B, slot));
     }
     wm_state* s = *slot;
-    if (s->pending) return fail(WM_E_STATE, "this slot still holds a pass that was not waited for");
     s->trace_id = slot == &m->cached ? 1 : 2 + (int)(slot - m->slots);
     // The whole pass — encoder, prefill, greedy loop — goes on the slot's own stream: four slots are then four hardware
     // queues, which is what the chip runs concurrently (a fifth queue, e.g. a shared encoder stream, lands on a pipe that
     // already serves one of them and the two take turns: 22.3 vs 20.8 ms per pass at four passes in flight).
     // WM_ENC_ON_MODEL_STREAM=1 restores the shared encoder stream for A/B runs.
-    static const bool enc_on_lane = getenv("WM_ENC_ON_MODEL_STREAM") == nullptr;
+    static const bool enc_on_lane = wm_env("WM_ENC_ON_MODEL_STREAM") == nullptr;
     hipStream_t est = enc_on_lane ? s->lanes[0].st : m->stream;
     s->has_enc = s->has_cross = false;
     s->host_len = 0;
@@ -1418,7 +1459,7 @@ static int submit_on(wm_model* m, wm_state** slot, const float* mel, int mel_on_
     s->enc_stream = est;
     s->has_enc = s->has_cross = true;
     s->last_mel = mel_dev;
-    if (getenv("WM_TRACE_HOST")) {
+    if (wm_env("WM_TRACE_HOST")) {
         const auto tt1 = std::chrono::steady_clock::now();
         (void)hipStreamSynchronize(m->stream);
         fprintf(stderr, "[wm] encoder: enqueue %.3f ms, done after %.3f ms\n", std::chrono::duration<double>(tt1 - tt0).count() * 1e3,
@@ -1582,6 +1623,7 @@ extern "C" int wm_transcribe_pcm(wm_model* m, const float* pcm, const int32_t* n
 // ---- measurement helpers ------------------------------------------------------------------------------------------------
 extern "C" int wm_bench_bytes(wm_model* m, wm_state* s, int which, double* bytes) {
     if (!m || !s || !bytes) return fail(WM_E_ARG, "null argument");
+    if (!state_is_live(s) || s->m != m) return fail(WM_E_ARG, "stale or foreign state handle");
     const wm_dims& c = m->cfg.dims;
     const double d = c.d_model, H = c.n_heads, B = s->B;
     const double ks = dt_size(m->cfg.kv_dtype), ws = dt_size(m->cfg.compute_dtype);
@@ -1606,6 +1648,7 @@ extern "C" int wm_bench_bytes(wm_model* m, wm_state* s, int which, double* bytes
 
 extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, float* avg_us) {
     if (!m || !s || !avg_us || reps <= 0) return fail(WM_E_ARG, "bad argument");
+    WMCHK(check_state(m, s, s->B));
     if (!s->has_cross) return fail(WM_E_STATE, "state has no cross K/V (call wm_encode first)");
     HIPCHK(hipSetDevice(m->device));
     hipStream_t st = m->stream;
@@ -1643,6 +1686,7 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
         HIPCHK(hipEventRecord(e1, st));
         HIPCHK(hipEventSynchronize(e1));
         (void)hipGraphExecDestroy(ge);
+#ifdef WM_DEV
     } else if (which >= 20 && which < 40) {
         // debug chains of the REAL decode-step launches (layer 0 shapes), 40 per graph
         const wm_dims& c = m->cfg.dims;
@@ -1777,6 +1821,7 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
         (void)hipEventDestroy(e1);
         *avg_us = ms40 * 1000.0f / (float)(reps * 40);
         return 0;
+#endif  // WM_DEV
     } else if (which == WM_KERNEL_ENCODER) {
         if (!s->last_mel) return fail(WM_E_STATE, "no mel was encoded into this state");
         WMCHK(run_encoder(m, s, s->last_mel, s->B, st));

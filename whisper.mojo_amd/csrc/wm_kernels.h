@@ -2,7 +2,33 @@
 #pragma once
 #include "wm_device.h"
 
+#include <atomic>
+#include <cstdlib>
+
+// Developer switches (A/B knobs, timelines, debug chains) exist only in the -DWM_DEV build (libwhispermi_dev.so, built by
+// `python whisper.mojo_amd/build.py --dev`).  In the product library wm_env() is a constant nullptr, so every switch folds
+// to its measured-best default at compile time and no launch path reads the environment.
+#ifdef WM_DEV
+static inline const char* wm_env(const char* name) { return std::getenv(name); }
+#else
+static constexpr const char* wm_env(const char*) { return nullptr; }
+#endif
+
 namespace wm {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: remember it per device (the C-ABI
+// takes a device index; two models on two GPUs in one process both need it).  Returns the HIP status.
+template <typename F> static inline hipError_t ensure_dyn_lds(F* kernel, int bytes) {
+    static std::atomic<unsigned long long> done{0};  // one flag bit per device, per kernel instantiation
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 // Per-state decode control block, resident in HBM so that a captured decode step can be replayed unchanged.
 struct StepCtl {
@@ -67,6 +93,7 @@ struct DecLinearParams {
     int ts_id;
 };
 template <typename TW> void launch_dec_linear(const DecLinearParams& p, hipStream_t st);
+bool dec_linear_supports_k(int K);  // K/32 k-steps must split into NW <= 16 waves x KPW <= 4 steps (checked at model load)
 template <typename TW> void launch_dec_logits(const DecLinearParams& p, hipStream_t st);
 int dec_logits_parts(int N);  // fused-argmax partials per utterance that launch_dec_logits writes (amax_stride must cover them)
 

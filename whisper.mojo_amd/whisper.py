@@ -10,6 +10,7 @@ tensors), 16-bit operand / KV-cache dtypes, Whisper-base dims."""
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -60,6 +61,10 @@ class KVCache:
         h = C.c_void_p()
         _lib.check(_lib.lib().wm_state_new(model._h, batch, C.byref(h)))
         self._h = h
+        # the model owns the device arenas of its caches (wm_model_free frees them): remember WHICH loaded model this is, so
+        # a cache that outlives a reload / close() neither frees nor uses memory that went away with the old model
+        self._model_h = model._h.value
+        model._caches.add(self)
 
     @property
     def current_len(self) -> int:
@@ -69,9 +74,14 @@ class KVCache:
     def reset(self):
         _lib.check(_lib.lib().wm_state_reset(self._h))
 
+    def _invalidate(self):
+        """Whisper.close() / load(): the library freed this cache's state together with its model."""
+        self._h = None
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h and getattr(self.model, "_h", None):
+        mh = getattr(getattr(self, "model", None), "_h", None)
+        if h and mh is not None and mh.value == getattr(self, "_model_h", None):
             _lib.lib().wm_state_free(h)
 
 
@@ -135,6 +145,7 @@ class Whisper:
         self.max_batch = max_batch
         self.device = device
         self._h = None
+        self._caches = weakref.WeakSet()  # live KVCaches of the loaded model
         self.encoder = WhisperEncoder(self)
         self.decoder = WhisperDecoder(self)
 
@@ -160,7 +171,11 @@ class Whisper:
     def close(self):
         h, self._h = self._h, None
         if h:
-            _lib.lib().wm_model_free(h)
+            for c in list(self._caches):
+                c._invalidate()
+            self._caches.clear()
+            self._pending = {}
+            _lib.lib().wm_model_free(h)  # also frees every state (KVCache arena, pipeline slot) created on it
 
     def __del__(self):
         try:
