@@ -138,15 +138,16 @@ def test_tiny_fp32_reachable_eot_long(hip, oracle_mod, tiny_cfg, tiny_weights):
 
 
 def test_tiny_fp32_context_edge_448(hip, oracle_mod, tiny_cfg, tiny_weights):
-    """The 448-row decoder context (KVCache(n_layers, d_model, 448), whisper.mojo:193): the longest stream the cache holds,
-    n_prompt + 1 + 443 = 448 ids, the last K/V row written at index 446.  ids equal the oracle's up to an oracle near-tie."""
+    """The 448-row decoder context (KVCache(n_layers, d_model, 448), whisper.mojo:193): the longest stream the cache holds —
+    the 4 prompt rows + 444 fed-back ids fill rows 0..447 (the last generated id needs no row), 449 ids in all.  ids equal
+    the oracle's up to an oracle near-tie; one iteration more is refused."""
     mel = synth_mels(tiny_cfg, [1005])
     ref = oracle_mod.OracleModel(tiny_cfg, tiny_weights)
     m = make_model(tiny_cfg, tiny_weights, max_batch=1)
-    n = tiny_cfg.n_text_ctx - 4 - 1
+    n = tiny_cfg.n_text_ctx - 4
     want, lg = ref.transcribe(mel=mel[0], max_loop=n, ignore_eot=True, want_logits=True)
     got = m.transcribe_batch(mel, max_loop=n, ignore_eot=True)[0]
-    assert len(got) == len(want) == tiny_cfg.n_text_ctx
+    assert len(got) == len(want) == tiny_cfg.n_text_ctx + 1
     i = first_divergence(got, want.tolist())
     assert i is None or margins_of(lg[i - 4:i - 3])[0] < MARGIN_TOL, (i, got[i], want[i])
     from whisper_mojo_amd import _lib
@@ -160,11 +161,11 @@ def test_micro_longest_stream_ids(hip, oracle_mod, micro_cfg, micro_weights):
     mels = synth.synth_mels(micro_cfg, 200, 3)
     ref = oracle_mod.OracleModel(micro_cfg, micro_weights)
     m = make_model(micro_cfg, micro_weights, max_batch=3)
-    n = micro_cfg.n_text_ctx - 4 - 1
+    n = micro_cfg.n_text_ctx - 4
     got = m.transcribe_batch(mels, prompt=(1, 2, 3, 4), eot=-1, max_loop=n)
     for b in range(3):
         want, lg = ref.transcribe(mel=mels[b], prompt=(1, 2, 3, 4), eot=-1, max_loop=n, want_logits=True)
-        assert len(got[b]) == micro_cfg.n_text_ctx
+        assert len(got[b]) == micro_cfg.n_text_ctx + 1
         i = first_divergence(got[b], want.tolist())
         assert i is None or margins_of(lg[i - 4:i - 3])[0] < MARGIN_TOL
 
