@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
                 for (int nb = 0; nb < 2; ++nb)
                     if (have[nb]) {
 #pragma unroll
-                        for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag_nt<TW>(wp[nb] + i * 32);
+                        for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + i * 32);
                     }
                 if (gi < K / 2) *reinterpret_cast<f32x4*>(&s_gb[0][0] + 4 * gi) = gbv;
                 __syncthreads();
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
 #pragma unroll
                 for (int nb = 0; nb < nbn; ++nb)
 #pragma unroll
-                    for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag_nt<TW>(wp[nb] + (c * CHK + i) * 32);
+                    for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + (c * CHK + i) * 32);
             }
 #pragma unroll
             for (int i = 0; i < CHK; ++i) {
@@ -480,14 +480,6 @@ template void launch_dec_logits<f16>(const DecLinearParams&, hipStream_t);
 // attn_combine, or the normalised output directly when the chunk is the whole sequence.
 // Scale after the dot product and max initialised to -1e10 follow layers.mojo:196,212 (the mask branch at :213 is a
 // no-op for j <= len-1 and is omitted).
-// write-through (sc1) 16-byte store: the bytes are in memory once the storing wave's s_waitcnt vmcnt(0) returns, so a
-// workgroup on another CU / XCD may read them after an agent-scope acquire without this side running a release fence
-// (cdna_hip_programming.md Guideline 16, R1)
-__device__ __forceinline__ void store_sc1_f32x4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, f32x4 v) {
-    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)byte_off, 0, /*aux: sc1*/ 16);
-}
-
 template <typename TKV, int LPH, bool FAST, bool NT, int U, int NQ = 1>
 __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecParams p) {
     // NQ > 1 (prompt prefill, cross-attention): the workgroup of utterance b serves the NQ query rows t * B + b from ONE
@@ -592,10 +584,6 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecParams p) {
             }
         }
     }
-    // partials of all utterances live in one buffer: descriptors from kernel arguments only (wave-uniform by construction)
-    const bool fused_merge = p.ticket != nullptr;
-    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.part_o, 0, fused_merge ? p.part_o_bytes : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_ml = __builtin_amdgcn_make_buffer_rsrc(p.part_ml, 0, fused_merge ? p.part_ml_bytes : 0, 0x00020000);
     // merge the RPS row slots (lanes of one LPH group carry identical m, l), one query position after the other
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
@@ -619,73 +607,15 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecParams p) {
                 for (int e = 0; e < EPL; ++e) o[e] += wgt * s_red[tt * EPL + e];
             }
             const size_t orow = (size_t)b + (size_t)t * qstride;
-            if (fused_merge) {  // write-through stores: the last-arriving chunk workgroup of this utterance reads them below
-                const unsigned off = (unsigned)(((orow * p.nsplit + split) * p.d + h * 64 + e0) * sizeof(float));
+            float* po = p.direct_out ? p.direct_out + orow * p.d + h * 64 + e0
+                                     : p.part_o + (orow * p.nsplit + split) * p.d + h * 64 + e0;
+            const float norm = p.direct_out ? 1.0f / L : 1.0f;
 #pragma unroll
-                for (int e = 0; e < EPL; e += 4) store_sc1_f32x4(rs_o, off + e * 4, f32x4{o[e], o[e + 1], o[e + 2], o[e + 3]});
-                if ((c % LPH) == 0) {
-                    const unsigned offm = (unsigned)((((orow * p.nsplit + split) * p.H + h) * 2) * sizeof(float));
-                    typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned u32x2;
-                    const u32x2 mlv = {__builtin_bit_cast(unsigned, M), __builtin_bit_cast(unsigned, L)};
-                    __builtin_amdgcn_raw_buffer_store_b64(mlv, rs_ml, (int)offm, 0, 16);
-                }
-            } else {
-                float* po = p.direct_out ? p.direct_out + orow * p.d + h * 64 + e0
-                                         : p.part_o + (orow * p.nsplit + split) * p.d + h * 64 + e0;
-                const float norm = p.direct_out ? 1.0f / L : 1.0f;
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) po[e] = o[e] * norm;
-                if (!p.direct_out && (c % LPH) == 0) {
-                    float* pml = p.part_ml + ((orow * p.nsplit + split) * p.H + h) * 2;
-                    pml[0] = M;
-                    pml[1] = L;
-                }
-            }
-        }
-    }
-    if (fused_merge) {
-        // Chunk merge inside the launch (replaces the attn_combine launch): every chunk workgroup of utterance b takes a
-        // ticket after its partials have left; the one that draws the last ticket merges all nsplit partials in the fixed
-        // order s = 0 .. nsplit-1, so the result does not depend on which workgroup that is (bitwise reproducible).
-        // Protocol = Guideline 16, counter form: sc1 stores -> every storing wave s_waitcnt vmcnt(0) -> workgroup barrier ->
-        // one relaxed agent-scope fetch_add; last arriver: one agent-scope acquire -> s_waitcnt vmcnt(0) -> barrier -> plain
-        // loads.  The counter only ever grows (nsplit tickets per launch): no reset inside a captured graph.
-        __shared__ int s_last;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned old = __hip_atomic_fetch_add(p.ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = ((old + 1u) % (unsigned)p.nsplit) == 0u;
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            s_last = last;
-        }
-        __syncthreads();
-        if (s_last) {
-            const int ns = p.nsplit;
-#pragma unroll
-            for (int t = 0; t < NQ; ++t) {
-                const size_t orow = (size_t)b + (size_t)t * qstride;
-                for (int col = threadIdx.x; col < p.d; col += blockDim.x) {
-                    const int hh = col >> 6;
-                    const float* ml = p.part_ml + (orow * ns * p.H + hh) * 2;  // chunk s at + s * H * 2
-                    const float* po = p.part_o + orow * ns * p.d + col;         // chunk s at + s * d
-                    float Mx = -1e30f;
-                    for (int s = 0; s < ns; ++s) {
-                        const float m = ml[(size_t)s * p.H * 2], l = ml[(size_t)s * p.H * 2 + 1];
-                        Mx = fmaxf(Mx, l > 0.f ? m : -1e30f);
-                    }
-                    float Ls = 0.f, acc_o = 0.f;
-                    for (int s = 0; s < ns; ++s) {
-                        const float m = ml[(size_t)s * p.H * 2], l = ml[(size_t)s * p.H * 2 + 1];
-                        const float wgt = l > 0.f ? expf(m - Mx) : 0.f;
-                        Ls += wgt * l;
-                        acc_o += wgt * po[(size_t)s * p.d];
-                    }
-                    p.merged[orow * p.d + col] = acc_o * (1.0f / Ls);
-                }
+            for (int e = 0; e < EPL; ++e) po[e] = o[e] * norm;
+            if (!p.direct_out && (c % LPH) == 0) {
+                float* pml = p.part_ml + ((orow * p.nsplit + split) * p.H + h) * 2;
+                pml[0] = M;
+                pml[1] = L;
             }
         }
     }

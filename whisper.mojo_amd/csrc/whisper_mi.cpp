@@ -230,7 +230,6 @@ struct wm_state {
     std::vector<int32_t> sup_cached, bsup_cached;
     bool masks_valid = false;
     static const int PREFILL_MAX = 16;  // prompt positions decoded in one pass (= the n_prompt bound of wm_decode_opts)
-    DevBuf ticket;  // [B * PREFILL_MAX] arrival counters of the cross-attention's in-kernel chunk merge (monotonic)
     DevBuf dx, dq, dattn, dhid, part_o, part_ml, logits, amax_val, amax_idx, tok, pos, tok_rows, pos_rows, ctl, out_tokens, n_tokens, finished;
     int npart = 0;  // fused-argmax partials per utterance = workgroups per row block of the logits kernel
 };
@@ -669,7 +668,7 @@ extern "C" void wm_state_free(wm_state* s) {
     if (s->enc_done) (void)hipEventDestroy(s->enc_done);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     DevBuf* bs[] = {&s->mel_dev, &s->mel_t, &s->h1, &s->x, &s->xn, &s->qkv, &s->ao, &s->hid, &s->enc_t, &s->enc_f,
-                    &s->cross_kv, &s->self_kv, &s->ticket, &s->dx, &s->dq, &s->dattn, &s->dhid, &s->part_o, &s->part_ml, &s->logits, &s->amax_val, &s->amax_idx, &s->mask_steady, &s->mask_begin,
+                    &s->cross_kv, &s->self_kv, &s->dx, &s->dq, &s->dattn, &s->dhid, &s->part_o, &s->part_ml, &s->logits, &s->amax_val, &s->amax_idx, &s->mask_steady, &s->mask_begin,
                     &s->tok, &s->pos, &s->tok_rows, &s->pos_rows, &s->ctl, &s->out_tokens, &s->n_tokens, &s->finished};
     for (DevBuf* b : bs) b->release();
     delete s;
@@ -733,7 +732,6 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
     A(s->dhid, R * c.ffn * 4);
     A(s->part_o, R * s->nsplit * d * 4);
     A(s->part_ml, R * s->nsplit * c.n_heads * 2 * 4);
-    A(s->ticket, R * 4, true);
     A(s->tok_rows, R * 4, true);
     A(s->pos_rows, R * 4, true);
     A(s->logits, (size_t)B * m->Vpad * 4);
@@ -805,7 +803,6 @@ extern "C" int wm_state_reset(wm_state* s) {
     HIPCHK(hipMemsetAsync(s->ctl.p, 0, s->ctl.bytes, st));
     HIPCHK(hipMemsetAsync(s->n_tokens.p, 0, s->n_tokens.bytes, st));
     HIPCHK(hipMemsetAsync(s->finished.p, 0, s->finished.bytes, st));
-    HIPCHK(hipMemsetAsync(s->ticket.p, 0, s->ticket.bytes, st));
     s->has_enc = s->has_cross = false;
     s->host_len = 0;
     return 0;
@@ -1011,10 +1008,6 @@ struct DecView {
 };
 static DecView whole_batch(wm_model* m, wm_state* s) { return DecView{0, s->B, m->stream, s->ctl.as<StepCtl>()}; }
 
-static bool fused_merge() {
-    static const bool off = wm_env("WM_NO_FUSED_MERGE") != nullptr;  // dev A/B: separate attn_combine launch as in round 1
-    return !off;
-}
 static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v, int P = 1) {
     const wm_dims& c = m->cfg.dims;
     const size_t d = c.d_model, ks = dt_size(m->cfg.kv_dtype);
@@ -1039,12 +1032,6 @@ static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v,
     a.nq = (P == 4 && !no_mq) ? 4 : 0;  // the reference's 4-token prompt: one K/V sweep for the four positions
     a.ts = (long long*)m->ts_buf.p;
     a.ts_id = s->trace_id;
-    if (fused_merge()) {  // the last-arriving chunk workgroup of an utterance merges its partials into dattn: no combine launch
-        a.ticket = s->ticket.as<unsigned>() + (size_t)v.b0;
-        a.merged = s->dattn.as<float>() + (size_t)v.b0 * d;
-        a.part_o_bytes = (int)std::min<size_t>(s->part_o.bytes - (size_t)v.b0 * s->nsplit * d * 4, 0x7fffffff);
-        a.part_ml_bytes = (int)std::min<size_t>(s->part_ml.bytes - (size_t)v.b0 * s->nsplit * c.n_heads * 2 * 4, 0x7fffffff);
-    }
     attn_decode_dispatch(m->cfg.kv_dtype, a, v.st);
 }
 
@@ -1148,11 +1135,10 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
             dec_linear_dispatch(T, p, st);
         }
         launch_cross_attn(m, s, l, v, P);
-        // (the chunk partials are merged inside the cross-attention launch by the utterance's last-arriving chunk workgroup;
-        // merging them in this projection's prologue was measured 14 us per layer slower: 96 workgroups each re-reading 295 KB)
-        if (!fused_merge())
-            launch_attn_combine(s->part_o.as<float>() + (size_t)v.b0 * s->nsplit * d, s->part_ml.as<float>() + (size_t)v.b0 * s->nsplit * c.n_heads * 2,
-                                dattn, B, s->nsplit, c.n_heads, c.d_model, st, (long long*)m->ts_buf.p, s->trace_id);
+        // (merging the chunk partials inside the projection's prologue was measured 14 us per layer SLOWER than this
+        // 3 us launch: 96 workgroups each re-reading 295 KB of partials)
+        launch_attn_combine(s->part_o.as<float>() + (size_t)v.b0 * s->nsplit * d, s->part_ml.as<float>() + (size_t)v.b0 * s->nsplit * c.n_heads * 2,
+                            dattn, B, s->nsplit, c.n_heads, c.d_model, st, (long long*)m->ts_buf.p, s->trace_id);
         proj_residual(dattn, c.d_model, w.co_w, w.co_b);
         {  // LN2 -> fc1 + GELU
             DecLinearParams p{};
@@ -1642,10 +1628,8 @@ extern "C" int wm_bench_bytes(wm_model* m, wm_state* s, int which, double* bytes
     const double d = c.d_model, H = c.n_heads, B = s->B;
     const double ks = dt_size(m->cfg.kv_dtype), ws = dt_size(m->cfg.compute_dtype);
     if (which == WM_KERNEL_CROSS_ATTN) {
-        // one layer: K and V rows of every utterance once + q in + chunk partials out, read back once by the in-kernel
-        // merge + the merged rows out (the K/V term, SURVEY §8d's B·2·d·s_kv·1500, is 98.8 % of it)
-        *bytes = B * 2.0 * c.n_audio_ctx * d * ks + B * d * 4 + (fused_merge() ? 2.0 : 1.0) * B * s->nsplit * (d + 2 * H) * 4 +
-                 (fused_merge() ? B * d * 4 : 0.0);
+        // one layer: K and V rows of every utterance once + q in + partials out
+        *bytes = B * 2.0 * c.n_audio_ctx * d * ks + B * d * 4 + B * s->nsplit * (d + 2 * H) * 4;
     } else if (which == WM_KERNEL_DECODE_STEP) {
         // every weight once per step, KV once per utterance, KV write; logits are NOT materialised
         // (fused argmax: only B x ceil(V/128) (value, index) partials are written and re-read)

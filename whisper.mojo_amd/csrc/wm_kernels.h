@@ -111,11 +111,6 @@ struct AttnDecParams {
     float* part_o;      // [B][nsplit][d]
     float* part_ml;     // [B][nsplit][H][2]
     float* direct_out;  // non-null (nsplit must be 1): write the normalised output [B][d] here, skip the partials
-    // in-kernel merge of the nsplit chunk partials (cross-attention): ticket[row] counts arrivals (monotonic, nsplit per
-    // launch); the chunk workgroup that arrives last writes the normalised output row(s) to `merged`.  null = partials only.
-    unsigned* ticket;
-    float* merged;  // [rows][d]
-    int part_o_bytes, part_ml_bytes;  // extents of part_o / part_ml (buffer descriptors of the write-through stores)
     int H, d, B;
     int rps;  // filled by the launcher
     long long* ts;  // developer timeline (null = off): see ts_put in kernels_decoder.hip
