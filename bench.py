@@ -10,6 +10,15 @@ already resident in HBM.  Rank 0 prints ONE JSON line.
     python bench.py --workload tiny_b1_f32            # BASELINE config 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W        # BASELINE config 4 at N=8
+
+Besides the contract's keys the line carries (all timed in this same run, N = 1 only):
+  value_with_h2d     the same K steps with the 61 MB of mels uploaded from pinned host memory INSIDE the timed region
+                     (SURVEY §8d's literal timed region; `value` keeps the mels resident, as the bench contract asks)
+  unpipelined        the K steps strictly one after another
+  natural            the reference's stop rule (eot 50257, <= 195 iterations, whisper.mojo:205-206) instead of the fixed 99
+  precision_ladder   the other precisions of the same model, a few steps each: bf16 operands + fp32 KV, everything fp32
+                     (the reference's own precision) at B = 64, and BASELINE config 2 (B = 1, fp32)
+  roofline / decode_step / decode_step_4_in_flight / encoder / cpu_baseline   as in round 1
 """
 import argparse
 import json
@@ -33,9 +42,16 @@ WORKLOADS = {
     "tiny_b1_f32": ("tiny", 1, "f32", "f32"),
     "base_b64_f16": ("base", 64, "f16", "f16"),
 }
+LADDER = ["tiny_b64_bf16_kv32", "tiny_b64_f32", "tiny_b1_f32"]
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 DECODE_STEPS = 99      # + 1 token from the prefill = 100 generated ids per utterance
+NATURAL_LOOP = 195     # whisper.mojo:205
 CLIP_SECONDS = 30.0
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def cpu_baseline(cfg, weights, mel, max_loop):
@@ -70,22 +86,208 @@ def cpu_baseline(cfg, weights, mel, max_loop):
 
 
 def pmc_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r1_pmc_traffic.json: separate
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r*_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 x2 FETCH correction applied).  Counters need
     their own serialised profiler passes, so they cannot be collected inside a timed bench run; null for other workloads."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-    if workload != "tiny_b64_bf16" or not os.path.exists(path):
+    if workload != "tiny_b64_bf16":
         return None
+    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            ks = json.load(open(path))["kernels"]
+            return next(v["traffic_bytes"] for k, v in ks.items() if k.startswith("attn_decode_kernel"))
+        except Exception:
+            continue
+    return None
+
+
+class Bench:
+    """One loaded model + its shard of synthetic mels, with the timing legs."""
+
+    def __init__(self, workload, batch, rank, world, local, weights_cache):
+        import ctypes as C
+        import torch
+        from whisper_mojo_amd import DT_BF16, DT_F16, DT_F32, WhisperConfig, _lib, dist as wdist
+        from whisper_mojo_amd.loader import WeightLoader
+        from whisper_mojo_amd.whisper import Whisper
+        self.C, self.torch, self._lib, self.wdist = C, torch, _lib, wdist
+        self.workload, self.world, self.rank = workload, world, rank
+        cfg_name, B, self.cdt, self.kdt = WORKLOADS[workload]
+        self.B = batch or B
+        self.cfg_name = cfg_name
+        self.cfg = WhisperConfig.tiny() if cfg_name == "tiny" else WhisperConfig.base()
+        DT = {"f32": DT_F32, "bf16": DT_BF16, "f16": DT_F16}
+        self.dev = torch.device("cuda", local)
+        self.L = _lib.lib()
+        if cfg_name not in weights_cache:  # synthetic weights (seed 0) in the reference's flat file format, by the library's C generator
+            dims = self.cfg.dims()
+            w = np.empty(self.cfg.weight_count(), np.float32)
+            self.L.wm_synth_weights(C.byref(dims), 0, w.ctypes.data_as(C.POINTER(C.c_float)))
+            weights_cache[cfg_name] = w
+        self.weights = weights_cache[cfg_name]
+        self.model = Whisper(self.cfg, compute_dtype=DT[self.cdt], kv_dtype=DT[self.kdt], max_batch=self.B, device=local)
+        self.model.load(WeightLoader.from_array(self.weights))
+        # this rank's shard of the global batch: utterance u uses mel seed 1000+u (SURVEY §8d config 3/4)
+        self.total = self.B * world
+        self.first, self.count = wdist.shard_range(self.total, rank, world)
+        # pinned host staging (the H2D-inclusive leg uploads from here) and the resident copy
+        self.mel_pinned = torch.empty((self.count, self.cfg.n_mels, self.cfg.n_frames), dtype=torch.float32).pin_memory()
+        self.mel_host = self.mel_pinned.numpy()
+        for i in range(self.count):
+            self.L.wm_synth_mel_host(1000 + self.first + i, self.cfg.n_mels, self.cfg.n_frames,
+                                     self.mel_host[i].ctypes.data_as(C.POINTER(C.c_float)))
+        self.mel_dev = self.mel_pinned.to(self.dev)  # resident in HBM before the timed region
+        self.last_counts = []
+
+    def close(self):
+        self.model.close()
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.torch.distributed.barrier()
+            self.torch.cuda.synchronize()
+
+    def run_steps(self, n, depth, max_loop=DECODE_STEPS, ignore_eot=True, mel=None, gather=True):
+        """n full passes, `depth` of them in flight through the library's pipeline slots (depth 1: wm_transcribe, synchronous).
+        Every pass does the full work; all n are complete (ids on the host, gathered) when this returns."""
+        m, mel = self.model, (self.mel_dev if mel is None else mel)
+        stride = 4 + 1 + max_loop
+        out = None
+        if depth <= 1:
+            for _ in range(n):
+                m.transcribe_batch(mel, max_loop=max_loop, ignore_eot=ignore_eot)
+                self.last_counts = [m.last_counts]
+                if gather:
+                    out = self.wdist.gather_tokens(m.last_tokens, m.last_counts, self.total, stride)
+            return out
+        # Groups of `depth` passes: submit them all, collect them all, THEN all-gather.  Four passes on four streams fill
+        # the four hardware queues the chip runs at a time and finish together anyway; an RCCL kernel issued while a slot's
+        # queue is busy could land on that queue's pipe and sit behind a whole pass, so the gathers go where the GPU is idle.
+        k = 0
+        while k < n:
+            g = min(depth, n - k)
+            for sl in range(g):
+                m.transcribe_submit(mel, slot=sl, max_loop=max_loop, ignore_eot=ignore_eot)
+            done = []
+            for sl in range(g):
+                m.transcribe_wait(sl)
+                done.append((m.last_tokens, m.last_counts))
+            if gather:
+                for toks, cnts in done:
+                    out = self.wdist.gather_tokens(toks, cnts, self.total, stride)
+            self.last_counts = [c for _, c in done]
+            k += g
+        return out
+
+    def timed(self, n, depth, **kw):
+        """(seconds, max over ranks; last gathered ids) for n passes bracketed by barrier + synchronize on both sides."""
+        self.sync()
+        t0 = time.perf_counter()
+        out = self.run_steps(n, depth, **kw)
+        self.sync()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            red = self.dev if self.torch.distributed.get_backend() == "nccl" else self.torch.device("cpu")
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device=red)
+            self.torch.distributed.all_reduce(t, op=self.torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
+    def setup_slots(self, depth, max_loop=2):
+        """allocate every slot's state and capture its step graph (set-up, like loading the weights — not a step)"""
+        if depth > 1:
+            for sl in range(depth):
+                self.model.transcribe_submit(self.mel_dev, slot=sl, max_loop=max_loop, ignore_eot=True)
+            for sl in range(depth):
+                self.model.transcribe_wait(sl)
+        else:
+            self.model.transcribe_batch(self.mel_dev, max_loop=max_loop, ignore_eot=True)
+        self.sync()
+
+    def rates(self, dt, n, gen_per_utt):
+        return (self.total * CLIP_SECONDS * n / dt, self.total * gen_per_utt * n / dt)
+
+    def kernel_timings(self, x4=True):
+        """HIP-event timings on the library's own streams (wm_bench_kernel): dominant kernel, decode step, encoder."""
+        C, L, _lib, m = self.C, self.L, self._lib, self.model
+        st = C.c_void_p()
+        _lib.check(L.wm_state_new(m._h, self.count, C.byref(st)))
+        _lib.check(L.wm_encode(m._h, st, C.c_void_p(self.mel_dev.data_ptr()), 1, self.count, None))
+        us, nbytes, step_us, step_bytes, enc_us = C.c_float(), C.c_double(), C.c_float(), C.c_double(), C.c_float()
+        _lib.check(L.wm_bench_kernel(m._h, st, _lib.KERNEL_CROSS_ATTN, 200, C.byref(us)))
+        _lib.check(L.wm_bench_bytes(m._h, st, _lib.KERNEL_CROSS_ATTN, C.byref(nbytes)))
+        _lib.check(L.wm_bench_kernel(m._h, st, _lib.KERNEL_DECODE_STEP, 50, C.byref(step_us)))
+        _lib.check(L.wm_bench_bytes(m._h, st, _lib.KERNEL_DECODE_STEP, C.byref(step_bytes)))
+        step4_us = None
+        if x4:
+            # the same step with four passes decoding at once (what the pipelined rate runs on): four states, four host threads
+            import threading
+            sts = [st]
+            for _ in range(3):
+                s2 = C.c_void_p()
+                _lib.check(L.wm_state_new(m._h, self.count, C.byref(s2)))
+                _lib.check(L.wm_encode(m._h, s2, C.c_void_p(self.mel_dev.data_ptr()), 1, self.count, None))
+                sts.append(s2)
+            us4 = [C.c_float() for _ in sts]
+            errs = []
+
+            def _chain(i):
+                try:
+                    _lib.check(L.wm_bench_kernel(m._h, sts[i], _lib.KERNEL_DECODE_STEP, 100, C.byref(us4[i])))
+                except Exception as e:  # noqa: BLE001
+                    errs.append(e)
+            th = [threading.Thread(target=_chain, args=(i,)) for i in range(4)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            if errs:
+                raise errs[0]
+            step4_us = max(u.value for u in us4)
+            for s2 in sts[1:]:
+                L.wm_state_free(s2)
+        _lib.check(L.wm_bench_kernel(m._h, st, _lib.KERNEL_ENCODER, 3, C.byref(enc_us)))
+        L.wm_state_free(st)
+        cfg = self.cfg
+        d, f, Lr, T = cfg.d_model, cfg.ffn, cfg.n_layers, cfg.n_audio_ctx
+        enc_flops = self.count * (2.0 * 3000 * d * cfg.n_mels * 3 + 2.0 * T * d * d * 3 +
+                                  Lr * (2.0 * T * d * d * 4 + 4.0 * T * T * d + 4.0 * T * d * f) + 2.0 * T * d * d * 2 * Lr)
+        achieved = nbytes.value / (us.value * 1e-6) / 1e9
+        step_gbs = step_bytes.value / (step_us.value * 1e-6) / 1e9
+        res = {
+            "roofline": {"bound": "hbm", "kernel": "attn_decode_kernel (decoder cross-attention, one layer, all utterances)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(self.workload),
+                         "bytes_per_launch": nbytes.value, "us_per_launch": round(us.value, 2)},
+            "decode_step": {"us": round(step_us.value, 1), "algorithmic_bytes": step_bytes.value,
+                            "GBps": round(step_gbs, 1), "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
+            "encoder": {"ms": round(enc_us.value / 1e3, 3), "TFLOPs": round(enc_flops / (enc_us.value * 1e-6) / 1e12, 1)},
+        }
+        if step4_us is not None:
+            agg = 4 * step_bytes.value / (step4_us * 1e-6) / 1e9
+            res["decode_step_4_in_flight"] = {"us_per_step_of_each_chain": round(step4_us, 1), "aggregate_GBps": round(agg, 1),
+                                              "frac_of_hbm_peak": round(agg / HBM_PEAK_GBS, 4)}
+        return res
+
+
+def ladder_entry(name, rank, world, local, weights_cache, depth):
+    """A few pipelined steps + the decode-step timing of another precision / batch of the same model (N = 1 leg)."""
+    b = Bench(name, 0, rank, world, local, weights_cache)
     try:
-        ks = json.load(open(path))["kernels"]
-        return next(v["traffic_bytes"] for k, v in ks.items() if k.startswith("attn_decode_kernel"))
-    except Exception:
-        return None
-
-
-def log(msg):
-    if int(os.environ.get("RANK", "0")) == 0:
-        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+        d = min(depth, 4)
+        b.setup_slots(d)
+        b.run_steps(d, d)
+        n = 2 * d
+        dt, _ = b.timed(n, d)
+        b.run_steps(1, 1)
+        seq, _ = b.timed(2, 1)
+        k = b.kernel_timings(x4=False)
+        rtf, tok = b.rates(dt, n, DECODE_STEPS + 1)
+        return {"workload": name, "operands": b.cdt, "kv": b.kdt, "utterances": b.B, "steps": n, "ms_per_step": round(dt / n * 1e3, 3),
+                "value": round(rtf, 1), "tokens_per_sec": round(tok, 1), "unpipelined_ms_per_step": round(seq / 2 * 1e3, 3),
+                "decode_step": k["decode_step"], "cross_attention": {k2: k["roofline"][k2] for k2 in ("achieved", "frac", "us_per_launch")},
+                "encoder": k["encoder"]}
+    finally:
+        b.close()
 
 
 def main():
@@ -99,14 +301,12 @@ def main():
     ap.add_argument("--no-x4", action="store_true", help="skip the four-chains-in-flight decode step timing (profiler runs: keeps every launch of the dominant kernel alone on the chip)")
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after another")
     ap.add_argument("--pipeline", type=int, default=4, choices=[1, 2, 3, 4, 5, 6, 7, 8], help="steps in flight (library pipeline slots)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the value_with_h2d / natural / precision_ladder legs (profiler and test runs)")
     ap.add_argument("--dump-ids", default="", help="rank 0 writes the gathered ids of the last timed step to this .npy file (tests)")
     args = ap.parse_args()
 
     import torch
-    from whisper_mojo_amd import DT_BF16, DT_F16, DT_F32, WhisperConfig, _lib, dist as wdist
-    from whisper_mojo_amd.loader import WeightLoader
-    from whisper_mojo_amd.whisper import Whisper
-    import ctypes as C
+    from whisper_mojo_amd import dist as wdist
 
     # rehearsal knobs (not used by the driver): WM_BENCH_BACKEND=gloo + WM_BENCH_SINGLE_DEVICE=1 run N ranks on ONE GPU
     backend = os.environ.get("WM_BENCH_BACKEND", "nccl")
@@ -115,185 +315,79 @@ def main():
         local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    cfg_name, B, cdt, kdt = WORKLOADS[args.workload]
-    if args.batch:
-        B = args.batch
-    cfg = WhisperConfig.tiny() if cfg_name == "tiny" else WhisperConfig.base()
-    DT = {"f32": DT_F32, "bf16": DT_BF16, "f16": DT_F16}
     torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    # synthetic weights (seed 0) in the reference's flat file format, generated by the library's C generator
-    L = _lib.lib()
-    dims = cfg.dims()
-    weights = np.empty(cfg.weight_count(), np.float32)
-    L.wm_synth_weights(C.byref(dims), 0, weights.ctypes.data_as(C.POINTER(C.c_float)))
-    log(f"weights generated ({weights.nbytes} bytes); loading model")
-    model = Whisper(cfg, compute_dtype=DT[cdt], kv_dtype=DT[kdt], max_batch=B, device=local)
-    model.load(WeightLoader.from_array(weights))
-
-    # this rank's shard of the global batch: utterance u uses mel seed 1000+u
-    total = B * world
-    first, count = wdist.shard_range(total, rank, world)
-    mel_host = np.empty((count, cfg.n_mels, cfg.n_frames), np.float32)
-    for i in range(count):
-        L.wm_synth_mel_host(1000 + first + i, cfg.n_mels, cfg.n_frames,
-                            mel_host[i].ctypes.data_as(C.POINTER(C.c_float)))
-    mel_dev = torch.from_numpy(mel_host).to(dev)  # resident in HBM before the timed region
+    depth = 1 if args.no_pipeline else args.pipeline
+    weights_cache = {}
+    log("generating weights, loading model, synthesising mels")
+    b = Bench(args.workload, args.batch, rank, world, local, weights_cache)
     stride = 4 + 1 + DECODE_STEPS
 
-    # Steps are issued through the library's pipeline slots (wm_transcribe_submit / _wait), `--pipeline` of them in flight:
-    # their encoders share the chip, then their latency/HBM-bound decode chains do.  Every step still does the full work;
-    # all K steps are complete (ids on the host, gathered) before the timed region closes.  --no-pipeline runs them one
-    # after another.
-    def run_steps(n):
-        out = None
-        if args.no_pipeline:
-            for _ in range(n):
-                model.transcribe_batch(mel_dev, max_loop=DECODE_STEPS, ignore_eot=True)
-                out = wdist.gather_tokens(model.last_tokens, model.last_counts, total, stride)
-            return out
-        # Groups of `depth` passes: submit them all, collect them all, THEN all-gather.  Four passes on four streams fill
-        # the four hardware queues the chip runs at a time and finish together anyway; an RCCL kernel issued while a slot's
-        # queue is busy could land on that queue's pipe and sit behind a whole pass, so the gathers go where the GPU is idle.
-        depth, k = args.pipeline, 0
-        while k < n:
-            g = min(depth, n - k)
-            for sl in range(g):
-                model.transcribe_submit(mel_dev, slot=sl, max_loop=DECODE_STEPS, ignore_eot=True)
-            done = []
-            for sl in range(g):
-                model.transcribe_wait(sl)
-                done.append((model.last_tokens, model.last_counts))
-            for toks, cnts in done:
-                out = wdist.gather_tokens(toks, cnts, total, stride)
-            k += g
-        return out
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-            torch.cuda.synchronize()
-
-    log("model loaded, mels resident; set-up of the pipeline slots")
-    if not args.no_pipeline:  # allocate every slot's state and capture its step graph (set-up, not a step)
-        for sl in range(args.pipeline):
-            model.transcribe_submit(mel_dev, slot=sl, max_loop=2, ignore_eot=True)
-        for sl in range(args.pipeline):
-            model.transcribe_wait(sl)
-    sync()
-    log("warm-up")
-    out = run_steps(args.warmup)
-    sync()
+    log("set-up of the pipeline slots; warm-up")
+    b.setup_slots(depth)
+    b.run_steps(args.warmup, depth)
     log("timed region")
-    t0 = time.perf_counter()
-    out = run_steps(args.steps)
-    sync()
-    dt = time.perf_counter() - t0
-    red_dev = dev if backend == "nccl" else torch.device("cpu")
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    assert out is not None and len(out) == total and all(len(o) == stride for o in out)
+    dt, out = b.timed(args.steps, depth)
+    assert out is not None and len(out) == b.total and all(len(o) == stride for o in out)
+    log(f"timed region done: {dt:.3f} s")
     if args.dump_ids and rank == 0:
         np.save(args.dump_ids, np.asarray(out, np.int32))
 
-    log(f"timed region done: {dt:.3f} s")
-    # the same K steps strictly one after another (no overlap between steps), for reference
-    seq_dt = None
-    if not args.no_pipeline and args.pipeline > 1:
-        saved, args.no_pipeline = args.no_pipeline, True
-        run_steps(1)
-        sync()
-        t1 = time.perf_counter()
-        run_steps(args.steps)
-        sync()
-        seq_dt = time.perf_counter() - t1
-        args.no_pipeline = saved
-        if world > 1:
-            t = torch.tensor([seq_dt], dtype=torch.float64, device=red_dev)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            seq_dt = float(t.item())
+    extras = {}
+    if depth > 1:  # the same K steps strictly one after another (no overlap between steps), for reference
+        b.run_steps(1, 1)
+        seq_dt, _ = b.timed(args.steps, 1)
+        extras["unpipelined"] = {"ms_per_step": round(seq_dt / args.steps * 1e3, 3), "value": round(b.rates(seq_dt, args.steps, 1)[0], 1)}
+    if world == 1 and not args.no_extras:
+        log("H2D-inclusive leg")
+        b.run_steps(min(depth, args.steps), depth, mel=b.mel_host)
+        h_dt, _ = b.timed(args.steps, depth, mel=b.mel_host)  # pinned host mels: every pass uploads its 61 MB inside the timed region
+        extras["value_with_h2d"] = {"value": round(b.rates(h_dt, args.steps, 1)[0], 1), "ms_per_step": round(h_dt / args.steps * 1e3, 3),
+                                    "note": "mels start in pinned host memory; each pass's hipMemcpyAsync is inside the timed region"}
+        log("natural decode mode (reference stop rule)")
+        nat_n = max(depth, 4)
+        b.setup_slots(depth, max_loop=NATURAL_LOOP)
+        n_dt, _ = b.timed(nat_n, depth, max_loop=NATURAL_LOOP, ignore_eot=False)
+        gen = float(np.mean([np.mean(c) for c in b.last_counts])) - 4
+        b.run_steps(1, 1, max_loop=NATURAL_LOOP, ignore_eot=False)
+        s_dt, _ = b.timed(2, 1, max_loop=NATURAL_LOOP, ignore_eot=False)  # synchronous form: polls "all finished" and stops early
+        extras["natural"] = {"stop_rule": "eot 50257 or 195 loop iterations (whisper.mojo:205-206)", "steps": nat_n,
+                             "ms_per_step": round(n_dt / nat_n * 1e3, 3), "value": round(b.rates(n_dt, nat_n, 1)[0], 1),
+                             "generated_ids_per_utterance": round(gen, 1), "tokens_per_sec": round(b.total * gen * nat_n / n_dt, 1),
+                             "synchronous_ms_per_step": round(s_dt / 2 * 1e3, 3),
+                             "note": "random-init weights almost never emit eot: natural mode runs to the 195-iteration bound"}
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        rtf = total * CLIP_SECONDS * args.steps / dt
-        tok_s = total * (DECODE_STEPS + 1) * args.steps / dt
-        # dominant kernel = decode cross-attention (cross-K/V streaming); timed with HIP events on the library's stream
-        st = C.c_void_p()
-        _lib.check(L.wm_state_new(model._h, count, C.byref(st)))
-        _lib.check(L.wm_encode(model._h, st, C.c_void_p(mel_dev.data_ptr()), 1, count, None))
-        us, nbytes, step_us, step_bytes, enc_us = C.c_float(), C.c_double(), C.c_float(), C.c_double(), C.c_float()
-        log("kernel timing: cross-attention")
-        _lib.check(L.wm_bench_kernel(model._h, st, _lib.KERNEL_CROSS_ATTN, 200, C.byref(us)))
-        _lib.check(L.wm_bench_bytes(model._h, st, _lib.KERNEL_CROSS_ATTN, C.byref(nbytes)))
-        log("kernel timing: decode step")
-        _lib.check(L.wm_bench_kernel(model._h, st, _lib.KERNEL_DECODE_STEP, 50, C.byref(step_us)))
-        _lib.check(L.wm_bench_bytes(model._h, st, _lib.KERNEL_DECODE_STEP, C.byref(step_bytes)))
-        step4_us = None
-        if not args.no_x4:
-            # the same step with four passes decoding at once (what the pipelined rate runs on): four states, four host threads
-            log("kernel timing: decode step, four chains in flight")
-            import threading
-            sts = [st]
-            for _ in range(3):
-                s2 = C.c_void_p()
-                _lib.check(L.wm_state_new(model._h, count, C.byref(s2)))
-                _lib.check(L.wm_encode(model._h, s2, C.c_void_p(mel_dev.data_ptr()), 1, count, None))
-                sts.append(s2)
-            us4 = [C.c_float() for _ in sts]
-            errs = []
-
-            def _chain(i):
-                try:
-                    _lib.check(L.wm_bench_kernel(model._h, sts[i], _lib.KERNEL_DECODE_STEP, 100, C.byref(us4[i])))
-                except Exception as e:  # noqa: BLE001
-                    errs.append(e)
-            th = [threading.Thread(target=_chain, args=(i,)) for i in range(4)]
-            [t.start() for t in th]
-            [t.join() for t in th]
-            if errs:
-                raise errs[0]
-            step4_us = max(u.value for u in us4)
-            for s2 in sts[1:]:
-                L.wm_state_free(s2)
-        log("kernel timing: encoder")
-        _lib.check(L.wm_bench_kernel(model._h, st, _lib.KERNEL_ENCODER, 3, C.byref(enc_us)))
-        L.wm_state_free(st)
-        achieved = nbytes.value / (us.value * 1e-6) / 1e9
-        step_gbs = step_bytes.value / (step_us.value * 1e-6) / 1e9
-        d, f, Lr, T = cfg.d_model, cfg.ffn, cfg.n_layers, cfg.n_audio_ctx
-        enc_flops = count * (2.0 * 3000 * d * cfg.n_mels * 3 + 2.0 * T * d * d * 3 +
-                             Lr * (2.0 * T * d * d * 4 + 4.0 * T * T * d + 4.0 * T * d * f) + 2.0 * T * d * d * 2 * Lr)
+        rtf, tok_s = b.rates(dt, args.steps, DECODE_STEPS + 1)
+        log("kernel timings (cross-attention, decode step, encoder)")
+        k = b.kernel_timings(x4=not args.no_x4)
         res = {
             "metric": "real-time-factor (audio-sec/wall-sec)", "value": round(rtf, 1), "unit": "x real-time",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cdt, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": b.cdt, "data": "synthetic",
             "tokens_per_sec": round(tok_s, 1),
-            "unpipelined": None if seq_dt is None else {"ms_per_step": round(seq_dt / args.steps * 1e3, 3),
-                                                        "value": round(total * CLIP_SECONDS * args.steps / seq_dt, 1)},
-            "config": {"workload": f"whisper-{cfg_name}, {B} synthetic 80x3000 mels per GPU ({total} total), greedy, 1 prefill + "
-                                   f"{DECODE_STEPS} decode steps, operands {cdt}, KV cache {kdt}, random-init weights (seed 0)",
-                       "name": args.workload, "utterances_per_gpu": B, "kv_dtype": kdt, "parallelism": f"dp{world}",
-                       "pipeline_depth": 1 if args.no_pipeline else args.pipeline},
-            "roofline": {"bound": "hbm", "kernel": "attn_decode_kernel (decoder cross-attention, one layer, all utterances)",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.workload),
-                         "bytes_per_launch": nbytes.value, "us_per_launch": round(us.value, 2)},
-            "decode_step": {"us": round(step_us.value, 1), "algorithmic_bytes": step_bytes.value,
-                            "GBps": round(step_gbs, 1), "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
-            "encoder": {"ms": round(enc_us.value / 1e3, 3), "TFLOPs": round(enc_flops / (enc_us.value * 1e-6) / 1e12, 1)},
+            "config": {"workload": f"whisper-{b.cfg_name}, {b.B} synthetic 80x3000 mels per GPU ({b.total} total) resident in HBM, greedy, "
+                                   f"1 prefill + {DECODE_STEPS} decode steps; GEMM operands {b.cdt} in the encoder AND the decoder (weights, "
+                                   f"activations fed to MFMA), KV cache {b.kdt} — narrower than BASELINE config 3's wording ('bf16 encoder "
+                                   "GEMMs'): see precision_ladder for the fp32-KV and all-fp32 runs; accumulation / LayerNorm / softmax / "
+                                   "residual fp32; random-init weights (seed 0)",
+                       "name": args.workload, "utterances_per_gpu": b.B, "kv_dtype": b.kdt, "parallelism": f"dp{world}",
+                       "pipeline_depth": depth},
         }
-        if step4_us is not None:
-            res["decode_step_4_in_flight"] = {"us_per_step_of_each_chain": round(step4_us, 1),
-                                              "aggregate_GBps": round(4 * step_bytes.value / (step4_us * 1e-6) / 1e9, 1),
-                                              "frac_of_hbm_peak": round(4 * step_bytes.value / (step4_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        res.update(extras)
+        res.update(k)
+        if world == 1 and not args.no_extras:
+            res["precision_ladder"] = []
+            for name in LADDER:
+                if name == args.workload:
+                    continue
+                log(f"precision ladder: {name}")
+                b.model.close()  # one model resident at a time
+                res["precision_ladder"].append(ladder_entry(name, rank, world, local, weights_cache, depth))
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline (oracle) ...")
-            res["cpu_baseline"] = cpu_baseline(cfg, weights, mel_host[0], DECODE_STEPS)
+            res["cpu_baseline"] = cpu_baseline(b.cfg, b.weights, b.mel_host[0], DECODE_STEPS)
         print(json.dumps(res), flush=True)
-    model.close()
+    b.close()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -47,6 +47,30 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: the cgroup quota when there is one (a GPU box shows 256 host cores to a job that
+    owns 16), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _cap_openmp_threads():
+    """libgomp defaults to one thread per visible core; with 256 visible and 16 usable every small parallel region of the
+    micro model spins against the quota (round 1's smoke() spent 90 s here).  OMP_NUM_THREADS, when set, wins."""
+    if os.environ.get("OMP_NUM_THREADS"):
+        return
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(max(1, min(usable_cpus(), 16)))
+    except OSError:
+        pass
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -87,6 +111,7 @@ def lib():
         L.wo_synth_fill.argtypes = [C.POINTER(WmDims), C.c_uint64, fp]
         L.wo_synth_fill.restype = C.c_size_t
         L.wo_synth_mel.argtypes = [C.c_uint64, C.c_int, C.c_int, fp]
+        _cap_openmp_threads()
         _lib = L
     return _lib
 

@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 
 F32_TOL = 5e-5      # fp32 mode: |logit - oracle| (values O(1); different summation order)
 MARGIN_TOL = 1e-3   # fp32 mode: a token may differ from the oracle's only where the oracle's own margin is below this
-BF16_TOL = 0.08     # bf16 operands + bf16 KV over 100 positions (measured 0.045 max on the 8 sampled utterances)
-F16_TOL = 0.012     # f16 operands + f16 KV, base dims (measured 0.006)
+BF16_TOL = 0.06     # bf16 operands + bf16 KV over 100 positions (measured: 0.031 max over the 8 sampled utterances x 100 positions)
+F16_TOL = 0.012     # f16 operands + f16 KV, base dims (measured: 0.0057 over 2 utterances x 40 positions)
 PROMPT = (50258, 50259, 50359, 50363)
 
 
@@ -216,7 +216,7 @@ def _sixteen_bit_case(oracle_mod, cfg, weights, dtype, tol, sampled, positions, 
 
 def test_config3_tiny_b64_bf16_against_oracle(hip, oracle_mod, tiny_cfg, tiny_weights):
     """BASELINE config 3 exactly as bench.py runs it: 64 clips, bf16 operands + bf16 KV cache, 1 prefill + 99 steps."""
-    worst, n_clear = _sixteen_bit_case(oracle_mod, tiny_cfg, tiny_weights, 1, BF16_TOL, [0, 7, 15, 16, 31, 40, 55, 63], 100, 150)
+    worst, n_clear = _sixteen_bit_case(oracle_mod, tiny_cfg, tiny_weights, 1, BF16_TOL, [0, 7, 15, 16, 31, 40, 55, 63], 100, 600)
     print(f"config 3: max |logit error| {worst:.4f} over 8 x 100 positions, {n_clear} positions with a clear margin")
 
 
@@ -225,7 +225,7 @@ def test_config5_base_b64_f16_against_oracle(hip, oracle_mod):
     from whisper_mojo_amd import WhisperConfig
     cfg = WhisperConfig.base()
     w = oracle_mod.synth_weights_c(cfg, 0)
-    worst, n_clear = _sixteen_bit_case(oracle_mod, cfg, w, 2, F16_TOL, [3, 60], 40, 40)
+    worst, n_clear = _sixteen_bit_case(oracle_mod, cfg, w, 2, F16_TOL, [3, 60], 40, 60)
     print(f"config 5: max |logit error| {worst:.4f} over 2 x 40 positions, {n_clear} positions with a clear margin")
 
 

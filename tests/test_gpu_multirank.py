@@ -33,7 +33,7 @@ def hip():
 
 def _bench(n, batch, dump, extra_env):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
-    args = ["bench.py", "--gpus", str(n), "--steps", "4", "--warmup", "0", "--no-cpu-baseline", "--no-x4", "--batch", str(batch),
+    args = ["bench.py", "--gpus", str(n), "--steps", "4", "--warmup", "0", "--no-cpu-baseline", "--no-x4", "--no-extras", "--batch", str(batch),
             "--dump-ids", dump]
     if n == 1:
         cmd = [sys.executable] + args

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
                 for (int nb = 0; nb < 2; ++nb)
                     if (have[nb]) {
 #pragma unroll
-                        for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + i * 32);
+                        for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag_nt<TW>(wp[nb] + i * 32);
                     }
                 if (gi < K / 2) *reinterpret_cast<f32x4*>(&s_gb[0][0] + 4 * gi) = gbv;
                 __syncthreads();
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
 #pragma unroll
                 for (int nb = 0; nb < nbn; ++nb)
 #pragma unroll
-                    for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + (c * CHK + i) * 32);
+                    for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag_nt<TW>(wp[nb] + (c * CHK + i) * 32);
             }
 #pragma unroll
             for (int i = 0; i < CHK; ++i) {
