@@ -53,6 +53,15 @@ typedef struct {
     int n_suppress;
     const int32_t* begin_suppress_tokens; /* ids that cannot be the FIRST generated token */
     int n_begin_suppress;
+    /* Timestamp rules, same row: the semantics of HF generate's WhisperTimeStampLogitsProcessor, applied after the two suppress
+     * masks inside the fused argmax — timestamps come in pairs, never decrease, the first generated id is a timestamp no
+     * later than timestamp_begin + max_initial_timestamp_index, <|notimestamps|> is never emitted, and whenever the
+     * probability mass of all admissible timestamps exceeds the most likely text id the id is a timestamp.  `eot` doubles as
+     * the processor's eos_token_id (ids below it are "normal text").  timestamp_begin <= 0 = off (the reference's behaviour;
+     * a zero-filled struct tail keeps it off). */
+    int timestamp_begin;             /* id of <|0.00|> (50364 for the multilingual vocabulary) */
+    int no_timestamps_token;         /* id of <|notimestamps|> (50363), or < 0 */
+    int max_initial_timestamp_index; /* HF generation config default 50 (= 1.00 s); < 0 = unlimited */
 } wm_decode_opts;
 
 typedef struct wm_model wm_model;

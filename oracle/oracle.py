@@ -105,6 +105,11 @@ def lib():
         L.wo_transcribe.restype = C.c_int
         L.wo_transcribe_ex.argtypes = [C.c_void_p, fp, fp, ip, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, C.c_int, ip, C.c_int, ip, fp]
         L.wo_transcribe_ex.restype = C.c_int
+        L.wo_transcribe_ts.argtypes = [C.c_void_p, fp, fp, ip, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, C.c_int, ip, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, ip, fp]
+        L.wo_transcribe_ts.restype = C.c_int
+        L.wo_timestamp_rules.argtypes = [fp, C.c_int, ip, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.wo_timestamp_rules.restype = None
         L.wo_teacher_forced.argtypes = [C.c_void_p, fp, ip, C.c_int, C.c_int, C.c_int, fp]
         L.wo_synth_count.argtypes = [C.POINTER(WmDims)]
         L.wo_synth_count.restype = C.c_size_t
@@ -186,6 +191,14 @@ def conv1d(inp, weight_T, bias, stride, padding, out_T=False):
     return out
 
 
+def timestamp_rules(scores, seq, timestamp_begin, no_timestamps, eos, max_initial=None):
+    """HF WhisperTimeStampLogitsProcessor.__call__ on one row of scores; returns the processed copy."""
+    t = _f32(scores).copy()
+    q = np.ascontiguousarray(np.asarray(list(seq) or [0], np.int32))
+    lib().wo_timestamp_rules(_fp(t), t.size, _ip(q), len(seq), timestamp_begin, no_timestamps, eos, -1 if max_initial is None else max_initial)
+    return t
+
+
 def argmax(x):
     x = _f32(x).ravel()
     return int(lib().wo_argmax(_fp(x), x.size))
@@ -248,7 +261,9 @@ class OracleModel:
         return out
 
     def transcribe(self, mel=None, enc_out=None, prompt=(50258, 50259, 50359, 50363), eot=50257, max_loop=195,
-                   pos_mode=0, ignore_eot=False, want_logits=False, suppress_tokens=(), begin_suppress_tokens=()):
+                   pos_mode=0, ignore_eot=False, want_logits=False, suppress_tokens=(), begin_suppress_tokens=(), timestamps=None):
+        """timestamps: None (the reference: raw argmax) or (timestamp_begin, no_timestamps_id, max_initial_timestamp_index | None):
+        HF's WhisperTimeStampLogitsProcessor after the suppress masks."""
         p = np.asarray(prompt, np.int32)
         toks = np.zeros(len(p) + 1 + max_loop, np.int32)
         logits = np.zeros((1 + max_loop, self.cfg.vocab_size), np.float32) if want_logits else None
@@ -256,8 +271,10 @@ class OracleModel:
         e = None if enc_out is None else _f32(enc_out)
         sup = np.asarray(list(suppress_tokens) or [0], np.int32)
         bsup = np.asarray(list(begin_suppress_tokens) or [0], np.int32)
-        n = lib().wo_transcribe_ex(self._h, _fp(m), _fp(e), _ip(p), len(p), eot, max_loop, pos_mode, int(ignore_eot),
-                                   _ip(sup), len(suppress_tokens), _ip(bsup), len(begin_suppress_tokens), _ip(toks), _fp(logits))
+        tb, no_ts, max_init = (0, -1, -1) if timestamps is None else (timestamps[0], timestamps[1], -1 if timestamps[2] is None else timestamps[2])
+        n = lib().wo_transcribe_ts(self._h, _fp(m), _fp(e), _ip(p), len(p), eot, max_loop, pos_mode, int(ignore_eot),
+                                   _ip(sup), len(suppress_tokens), _ip(bsup), len(begin_suppress_tokens), tb, no_ts, max_init,
+                                   _ip(toks), _fp(logits))
         toks = toks[:n].copy()
         if want_logits:
             return toks, logits[:n - len(p)].copy()

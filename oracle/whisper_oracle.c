@@ -667,6 +667,89 @@ int wo_transcribe_ex(const wo_model* m, const float* mel, const float* enc_in, c
     free(enc_out);
     return n;
 }
+/* SURVEY §8f rank 4, timestamp rules (absent from the reference): HF generate's WhisperTimeStampLogitsProcessor.__call__
+ * (transformers/generation/logits_process.py) for ONE sequence, statement for statement.  seq[0..n_seq) = the ids generated
+ * so far (everything after the prompt: the processor's input_ids[begin_index:]).  tb = timestamp_begin (= no_timestamps + 1),
+ * eos = the id below which "normal text tokens" live, max_init < 0 = no max_initial_timestamp_index.
+ *   1. <|notimestamps|> never;  2. timestamps come in pairs (after one: not a third in a row / after a pair's first: no text);
+ *   3. timestamps do not decrease, and a closed pair's value is not re-emitted;  4. the first id is a timestamp
+ *   <= tb + max_init;  5. if the probability MASS of all timestamps exceeds the single most likely text id, it must be a
+ *   timestamp (log-softmax's normaliser is common to both sides, so the raw scores are compared: logsumexp(ts) > max(text)). */
+void wo_timestamp_rules(float* scores, int V, const int32_t* seq, int n_seq, int tb, int no_ts, int eos, int max_init) {
+    if (no_ts >= 0 && no_ts < V) scores[no_ts] = -INFINITY;
+    const int last_ts = n_seq >= 1 && seq[n_seq - 1] >= tb;
+    const int pen_ts = n_seq < 2 || seq[n_seq - 2] >= tb;
+    if (last_ts) {
+        if (pen_ts) {
+            for (int i = tb; i < V; ++i) scores[i] = -INFINITY; /* has to be non-timestamp */
+        } else {
+            for (int i = 0; i < eos && i < V; ++i) scores[i] = -INFINITY; /* cannot be normal text tokens */
+        }
+    }
+    int t_last = -1;
+    for (int i = 0; i < n_seq; ++i)
+        if (seq[i] >= tb) t_last = seq[i]; /* timestamps[-1] */
+    if (t_last >= 0) {
+        const int ts_end = (last_ts && !pen_ts) ? t_last : t_last + 1; /* "avoid to emit <|0.00|> again" */
+        for (int i = tb; i < ts_end && i < V; ++i) scores[i] = -INFINITY;
+    }
+    if (n_seq == 0) { /* input_ids.shape[1] == begin_index */
+        for (int i = 0; i < tb && i < V; ++i) scores[i] = -INFINITY;
+        if (max_init >= 0)
+            for (int i = tb + max_init + 1; i < V; ++i) scores[i] = -INFINITY;
+    }
+    float m_ts = -INFINITY, m_text = -INFINITY;
+    for (int i = tb; i < V; ++i)
+        if (scores[i] > m_ts) m_ts = scores[i];
+    for (int i = 0; i < tb && i < V; ++i)
+        if (scores[i] > m_text) m_text = scores[i];
+    if (m_ts > -INFINITY) {
+        float sum = 0.f;
+        for (int i = tb; i < V; ++i) sum += expf(scores[i] - m_ts);
+        const float lse = m_ts + logf(sum);
+        if (lse > m_text)
+            for (int i = 0; i < tb && i < V; ++i) scores[i] = -INFINITY;
+    }
+}
+
+/* wo_transcribe_ex + the timestamp rules (tb > 0) applied after the two suppress masks, as HF generate orders its processors. */
+int wo_transcribe_ts(const wo_model* m, const float* mel, const float* enc_in, const int32_t* prompt, int n_prompt, int eot,
+                     int max_loop, int pos_mode, int ignore_eot, const int32_t* sup, int n_sup, const int32_t* bsup, int n_bsup,
+                     int tb, int no_ts, int max_init, int32_t* tokens_out, float* logits_out) {
+    const int d = m->cfg.d_model, T = m->cfg.n_audio_ctx, V = m->cfg.vocab;
+    float* enc_out = (float*)malloc(sizeof(float) * (size_t)T * d);
+    if (enc_in)
+        memcpy(enc_out, enc_in, sizeof(float) * (size_t)T * d);
+    else
+        wo_encode(m, mel, enc_out);
+    wo_cache* cache = wo_cache_new(m, m->cfg.n_text_ctx);
+    float* logits = (float*)malloc(sizeof(float) * (size_t)V);
+    int n = 0, row = 0;
+    for (int i = 0; i < n_prompt; ++i) tokens_out[n++] = prompt[i];
+    wo_decoder_forward(m, prompt, n_prompt, enc_out, cache, 0, logits);
+    if (logits_out) memcpy(logits_out + (size_t)(row++) * V, logits, sizeof(float) * V);
+    suppress(logits, sup, n_sup, V);
+    suppress(logits, bsup, n_bsup, V);
+    if (tb > 0) wo_timestamp_rules(logits, V, tokens_out + n_prompt, 0, tb, no_ts, eot, max_init);
+    int next = wo_argmax(logits, V);
+    tokens_out[n++] = next;
+    for (int it = 0; it < max_loop; ++it) {
+        if (!ignore_eot && next == eot) break;
+        int32_t last = next;
+        int start_pos = pos_mode == 0 ? cache->layers[0].current_len - 1 : cache->layers[0].current_len;
+        wo_decoder_forward(m, &last, 1, enc_out, cache, start_pos, logits);
+        if (logits_out) memcpy(logits_out + (size_t)(row++) * V, logits, sizeof(float) * V);
+        suppress(logits, sup, n_sup, V);
+        if (tb > 0) wo_timestamp_rules(logits, V, tokens_out + n_prompt, n - n_prompt, tb, no_ts, eot, max_init);
+        next = wo_argmax(logits, V);
+        tokens_out[n++] = next;
+    }
+    free(logits);
+    wo_cache_free(cache);
+    free(enc_out);
+    return n;
+}
+
 int wo_transcribe(const wo_model* m, const float* mel, const float* enc_in, const int32_t* prompt, int n_prompt,
                   int eot, int max_loop, int pos_mode, int ignore_eot, int32_t* tokens_out, float* logits_out) {
     return wo_transcribe_ex(m, mel, enc_in, prompt, n_prompt, eot, max_loop, pos_mode, ignore_eot, NULL, 0, NULL, 0, tokens_out,

@@ -31,7 +31,8 @@ class WmDecodeOpts(C.Structure):
     _fields_ = [("prompt", C.POINTER(C.c_int32)), ("n_prompt", C.c_int), ("eot", C.c_int), ("max_loop", C.c_int),
                 ("pos_mode", C.c_int), ("ignore_eot", C.c_int),
                 ("suppress_tokens", C.POINTER(C.c_int32)), ("n_suppress", C.c_int),
-                ("begin_suppress_tokens", C.POINTER(C.c_int32)), ("n_begin_suppress", C.c_int)]
+                ("begin_suppress_tokens", C.POINTER(C.c_int32)), ("n_begin_suppress", C.c_int),
+                ("timestamp_begin", C.c_int), ("no_timestamps_token", C.c_int), ("max_initial_timestamp_index", C.c_int)]
 
 
 class WhisperMiError(RuntimeError):

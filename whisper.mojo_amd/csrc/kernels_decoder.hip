@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
                 for (int nb = 0; nb < 2; ++nb)
                     if (have[nb]) {
 #pragma unroll
-                        for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag_nt<TW>(wp[nb] + i * 32);
+                        for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + i * 32);
                     }
                 if (gi < K / 2) *reinterpret_cast<f32x4*>(&s_gb[0][0] + 4 * gi) = gbv;
                 __syncthreads();
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
 #pragma unroll
                 for (int nb = 0; nb < nbn; ++nb)
 #pragma unroll
-                    for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag_nt<TW>(wp[nb] + (c * CHK + i) * 32);
+                    for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + (c * CHK + i) * 32);
             }
 #pragma unroll
             for (int i = 0; i < CHK; ++i) {
@@ -388,21 +388,78 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
     if (p.amax_val) {
         // fused argmax, stage 1 (whisper_tensor.mojo:431-439: lowest index wins): this workgroup's best of its CT*16
         // columns per utterance.  Lane-local over 8 columns, 2 butterfly steps over the 4 lanes of a row, LDS over waves.
+        // Timestamp rules on (p.ts_state): "best" is the best admissible TEXT id of the utterance's range, and the workgroups
+        // that cover timestamp ids also reduce the admissible timestamps to (best value, its id, max, sum of exp(v - max)) —
+        // what stage 2 needs to compare the timestamps' probability mass with the best text id (HF rule 5).
+        const bool ts_on = p.ts_state != nullptr;
+        const bool wg_ts = ts_on && (int)((blockIdx.x + 1) * CT * 16) > p.ts_begin;  // workgroup-uniform
+        __shared__ float s_tv[8][NRB * 16], s_tm[8][NRB * 16], s_ts[8][NRB * 16];
+        __shared__ int s_ti[8][NRB * 16];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
             float bv = -INFINITY;
             int bi = 0x7fffffff;
+            int t_lo = 0, t_hi = 0x7fffffff, q_lo = 0, q_hi = 0;
+            if (ts_on) {
+                const TsState* stp = p.ts_state + row0 + min(rb * 16 + r16, nrows - 1);
+                t_lo = stp->text_lo;
+                t_hi = stp->text_hi;
+                q_lo = stp->ts_lo;
+                q_hi = stp->ts_hi;
+            }
+            float cand[2][4];
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n = n0[nb] + g * 4 + r;
                     const float v = acc[nb][rb][r] + (p.amax_mask ? p.amax_mask[min(n, p.N - 1)] : 0.f);  // 0 or -inf
-                    if (have[nb] && n < p.N && v > bv) {  // n increases through the loop: strict '>' keeps the lowest index
+                    cand[nb][r] = v;
+                    if (have[nb] && n < p.N && n >= t_lo && n < t_hi && v > bv) {  // n increases through the loop: strict '>' keeps the lowest index
                         bv = v;
                         bi = n;
                     }
                 }
+            if (wg_ts) {
+                float tv = -INFINITY, tsum = 0.f;
+                int ti = 0x7fffffff;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n0[nb] + g * 4 + r;
+                        if (have[nb] && n < p.N && n >= q_lo && n < q_hi && cand[nb][r] > tv) {
+                            tv = cand[nb][r];
+                            ti = n;
+                        }
+                    }
+                float tm = tv;  // the lane's max IS its best value
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n0[nb] + g * 4 + r;
+                        if (have[nb] && n < p.N && n >= q_lo && n < q_hi && cand[nb][r] > -INFINITY) tsum += expf(cand[nb][r] - tm);
+                    }
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {
+                    const float v2 = __shfl_xor(tv, o, 64), m2 = __shfl_xor(tm, o, 64), s2 = __shfl_xor(tsum, o, 64);
+                    const int i2 = __shfl_xor(ti, o, 64);
+                    if (v2 > tv || (v2 == tv && i2 < ti)) {
+                        tv = v2;
+                        ti = i2;
+                    }
+                    const float mn = fmaxf(tm, m2);
+                    tsum = (tsum > 0.f ? tsum * expf(tm - mn) : 0.f) + (s2 > 0.f ? s2 * expf(m2 - mn) : 0.f);
+                    tm = mn;
+                }
+                if (g == 0) {
+                    s_tv[w][rb * 16 + r16] = tv;
+                    s_ti[w][rb * 16 + r16] = ti;
+                    s_tm[w][rb * 16 + r16] = tm;
+                    s_ts[w][rb * 16 + r16] = tsum;
+                }
+            }
 #pragma unroll
             for (int o = 16; o <= 32; o <<= 1) {
                 const float v2 = __shfl_xor(bv, o, 64);
@@ -433,6 +490,26 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
             const size_t o = (size_t)(row0 + threadIdx.x) * p.amax_stride + blockIdx.x;
             p.amax_val[o] = bv;
             p.amax_idx[o] = bi;
+            if (wg_ts) {  // the 8 waves' timestamp partials, in wave order (deterministic)
+                float tv = s_tv[0][threadIdx.x], tm = s_tm[0][threadIdx.x], tsum = s_ts[0][threadIdx.x];
+                int ti = s_ti[0][threadIdx.x];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) {
+                    const float v2 = s_tv[k][threadIdx.x], m2 = s_tm[k][threadIdx.x], s2 = s_ts[k][threadIdx.x];
+                    const int i2 = s_ti[k][threadIdx.x];
+                    if (v2 > tv || (v2 == tv && i2 < ti)) {
+                        tv = v2;
+                        ti = i2;
+                    }
+                    const float mn = fmaxf(tm, m2);
+                    tsum = (tsum > 0.f ? tsum * expf(tm - mn) : 0.f) + (s2 > 0.f ? s2 * expf(m2 - mn) : 0.f);
+                    tm = mn;
+                }
+                p.ts_val[o] = tv;
+                p.ts_idx[o] = ti;
+                p.ts_m[o] = tm;
+                p.ts_s[o] = tsum;
+            }
         }
     }
 }
@@ -441,6 +518,7 @@ int dec_logits_tiles_per_wg(int N) {
     const int tiles = (N + 15) / 16;
     return std::max(1, std::min(16, (tiles + 255) / 256));
 }
+int dec_logits_ids_per_part(int N) { return dec_logits_tiles_per_wg(N) * 16; }
 int dec_logits_parts(int N) {
     const int tiles = (N + 15) / 16, ct = dec_logits_tiles_per_wg(N);
     return (tiles + ct - 1) / ct;
@@ -798,6 +876,44 @@ __global__ __launch_bounds__(1024) void argmax_step_kernel(ArgmaxParams p) {
         argmax_partials(p.pval + (size_t)b * p.npart, p.pidx + (size_t)b * p.npart, p.npart, best, idx);
     else
         argmax_block(p.logits + (size_t)b * p.ldl, p.V, best, idx);
+    if (p.ts_state) {
+        // Timestamp rules, the decision (HF WhisperTimeStampLogitsProcessor rule 5 + the final argmax): (best, idx) is the best
+        // admissible text id; if the admissible timestamps' probability mass exceeds it — logsumexp(ts) > best, the softmax
+        // normaliser being common — the id is the best admissible timestamp.  (Without that the argmax over both sets would
+        // still be a text id: logsumexp(ts) >= max(ts).)  Then the history and the NEXT argmax's ranges.
+        __shared__ int s_pick;
+        if (threadIdx.x == 0) {
+            float tv = -INFINITY, tm = -INFINITY, tsum = 0.f;
+            int ti = 0x7fffffff;
+            for (int k = p.ts_part0; k < p.npart; ++k) {  // <= a dozen parts, fixed order
+                const size_t o = (size_t)b * p.npart + k;
+                const float v2 = p.ts_val[o], m2 = p.ts_m[o], s2 = p.ts_s[o];
+                const int i2 = p.ts_idx[o];
+                if (v2 > tv || (v2 == tv && i2 < ti)) {
+                    tv = v2;
+                    ti = i2;
+                }
+                const float mn = fmaxf(tm, m2);
+                tsum = (tsum > 0.f ? tsum * expf(tm - mn) : 0.f) + (s2 > 0.f ? s2 * expf(m2 - mn) : 0.f);
+                tm = mn;
+            }
+            int pick = idx;
+            const bool have_text = (unsigned)idx < (unsigned)p.V;
+            if (tsum > 0.f && (!have_text || tm + logf(tsum) > best)) pick = ti;
+            if ((unsigned)pick >= (unsigned)p.V) pick = 0;
+            TsState st = p.ts_state[b];
+            const int is_ts = pick >= p.rules.tb;
+            st.pen_ts = st.n_gen + 1 < 2 ? 1 : st.last_ts;
+            st.last_ts = is_ts;
+            st.n_gen += 1;
+            if (is_ts) st.t_last = pick;
+            ts_next_ranges(st, p.rules);
+            p.ts_state[b] = st;
+            s_pick = pick;
+        }
+        __syncthreads();
+        idx = s_pick;
+    }
     // every candidate NaN / -inf (16-bit overflow, bad weights, a mask over the whole vocabulary): no comparison succeeded and
     // idx is still the sentinel — it must not become an embedding row index.  The reference's scan (whisper_tensor.mojo:431-439:
     // start at t[0], strict '>') returns index 0 in exactly these cases, and so does this.
@@ -849,6 +965,15 @@ __global__ void init_tokens_kernel(InitTokensParams p) {
                 p.tok_rows[i * p.B + b] = p.prompt[i];
                 p.pos_rows[i * p.B + b] = i;
             }
+        }
+        if (p.ts_state) {
+            TsState st;
+            st.n_gen = 0;
+            st.last_ts = 0;
+            st.pen_ts = 1;
+            st.t_last = -1;
+            ts_next_ranges(st, p.rules);
+            p.ts_state[b] = st;
         }
     }
     if (b == 0) {

@@ -230,6 +230,9 @@ struct wm_state {
     std::vector<int32_t> sup_cached, bsup_cached;
     bool masks_valid = false;
     static const int PREFILL_MAX = 16;  // prompt positions decoded in one pass (= the n_prompt bound of wm_decode_opts)
+    DevBuf ts_state, ts_val, ts_idx, ts_m, ts_s;  // timestamp rules: per-utterance history / ranges, per-part timestamp partials
+    TsRules graph_rules{};                         // rules baked into the captured step graph
+    int no_ts_cached = -1;
     DevBuf dx, dq, dattn, dhid, part_o, part_ml, logits, amax_val, amax_idx, tok, pos, tok_rows, pos_rows, ctl, out_tokens, n_tokens, finished;
     int npart = 0;  // fused-argmax partials per utterance = workgroups per row block of the logits kernel
 };
@@ -668,7 +671,7 @@ extern "C" void wm_state_free(wm_state* s) {
     if (s->enc_done) (void)hipEventDestroy(s->enc_done);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     DevBuf* bs[] = {&s->mel_dev, &s->mel_t, &s->h1, &s->x, &s->xn, &s->qkv, &s->ao, &s->hid, &s->enc_t, &s->enc_f,
-                    &s->cross_kv, &s->self_kv, &s->dx, &s->dq, &s->dattn, &s->dhid, &s->part_o, &s->part_ml, &s->logits, &s->amax_val, &s->amax_idx, &s->mask_steady, &s->mask_begin,
+                    &s->cross_kv, &s->self_kv, &s->dx, &s->dq, &s->dattn, &s->dhid, &s->part_o, &s->part_ml, &s->logits, &s->amax_val, &s->amax_idx, &s->ts_state, &s->ts_val, &s->ts_idx, &s->ts_m, &s->ts_s, &s->mask_steady, &s->mask_begin,
                     &s->tok, &s->pos, &s->tok_rows, &s->pos_rows, &s->ctl, &s->out_tokens, &s->n_tokens, &s->finished};
     for (DevBuf* b : bs) b->release();
     delete s;
@@ -738,6 +741,11 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
     s->npart = dec_logits_parts(c.vocab);
     A(s->amax_val, (size_t)B * s->npart * 4);
     A(s->amax_idx, (size_t)B * s->npart * 4);
+    A(s->ts_val, (size_t)B * s->npart * 4, true);
+    A(s->ts_idx, (size_t)B * s->npart * 4, true);
+    A(s->ts_m, (size_t)B * s->npart * 4, true);
+    A(s->ts_s, (size_t)B * s->npart * 4, true);
+    A(s->ts_state, (size_t)B * sizeof(TsState), true);
     A(s->mask_steady, (size_t)m->Vpad * 4, true);
     A(s->mask_begin, (size_t)m->Vpad * 4, true);
     A(s->tok, (size_t)B * 4, true);
@@ -1042,7 +1050,7 @@ static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v,
 // self-attention of position t sees keys 0..len+t (the causal mask of layers.mojo:309-318), logits only for the last
 // position.  Every row's arithmetic is what the single-position pass does for it, so the ids are the same bit for bit.
 static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_logits, bool full_logits = false,
-                        const float* mask = nullptr, int P = 1, bool embed = true) {
+                        const float* mask = nullptr, int P = 1, bool embed = true, const TsRules* rules = nullptr) {
     const wm_dims& c = m->cfg.dims;
     const int T = m->cfg.compute_dtype, KV = m->cfg.kv_dtype;
     const int B = v.nb * P;          // activation rows of this pass
@@ -1175,6 +1183,14 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
         p.amax_idx = s->amax_idx.as<int>() + (size_t)v.b0 * s->npart;
         p.amax_stride = s->npart;
         p.amax_mask = mask;
+        if (rules && rules->tb > 0) {  // timestamp rules: split the candidates by the utterances' admissible ranges
+            p.ts_state = s->ts_state.as<TsState>() + v.b0;
+            p.ts_begin = rules->tb;
+            p.ts_val = s->ts_val.as<float>() + (size_t)v.b0 * s->npart;
+            p.ts_idx = s->ts_idx.as<int>() + (size_t)v.b0 * s->npart;
+            p.ts_m = s->ts_m.as<float>() + (size_t)v.b0 * s->npart;
+            p.ts_s = s->ts_s.as<float>() + (size_t)v.b0 * s->npart;
+        }
         p.ts = (long long*)m->ts_buf.p;
         p.ts_id = s->trace_id;
         DISPATCH_DT(T, TT, launch_dec_logits<TT>(p, st));
@@ -1182,8 +1198,17 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
 }
 
 static ArgmaxParams argmax_params(wm_model* m, wm_state* s, const DecView& v, bool record, int eot, int ignore_eot,
-                                  bool advance = false, bool embed_next = false) {
+                                  bool advance = false, bool embed_next = false, const TsRules* rules = nullptr) {
     ArgmaxParams a{};
+    if (rules && rules->tb > 0) {
+        a.ts_state = s->ts_state.as<TsState>() + v.b0;
+        a.rules = *rules;
+        a.ts_val = s->ts_val.as<float>() + (size_t)v.b0 * s->npart;
+        a.ts_idx = s->ts_idx.as<int>() + (size_t)v.b0 * s->npart;
+        a.ts_m = s->ts_m.as<float>() + (size_t)v.b0 * s->npart;
+        a.ts_s = s->ts_s.as<float>() + (size_t)v.b0 * s->npart;
+        a.ts_part0 = rules->tb / dec_logits_ids_per_part(m->cfg.dims.vocab);
+    }
     a.logits = s->logits.as<float>() + (size_t)v.b0 * m->Vpad;
     a.pval = s->amax_val.as<float>() + (size_t)v.b0 * s->npart;
     a.pidx = s->amax_idx.as<int>() + (size_t)v.b0 * s->npart;
@@ -1281,14 +1306,24 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
     static const bool trace_phase = wm_env("WM_TRACE_HOST") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
     static const bool no_graph = wm_env("WM_NO_GRAPH") != nullptr;
-    const bool recapture = !s->graphs_valid || s->graph_eot != o->eot || s->graph_ignore != o->ignore_eot;
+    TsRules rules{};  // timestamp rules of this pass (tb <= 0: off)
+    rules.tb = o->timestamp_begin > 0 ? o->timestamp_begin : 0;
+    rules.eos = o->eot;
+    rules.max_init = o->max_initial_timestamp_index;
+    rules.vocab = m->cfg.dims.vocab;
+    const TsRules* rp = rules.tb > 0 ? &rules : nullptr;
+    const int no_ts = rp ? o->no_timestamps_token : -1;
+    const bool recapture = !s->graphs_valid || s->graph_eot != o->eot || s->graph_ignore != o->ignore_eot ||
+                           memcmp(&s->graph_rules, &rules, sizeof rules) != 0;
     const int first_pos = o->pos_mode == WM_POS_REF ? o->n_prompt - 1 : o->n_prompt;
     // logit masks (§8f rank 4): rebuilt only when the id lists change; always passed (all-zero = the reference's raw argmax)
     {
         std::vector<int32_t> sup(o->suppress_tokens, o->suppress_tokens + (o->suppress_tokens ? o->n_suppress : 0));
         std::vector<int32_t> bsup(o->begin_suppress_tokens, o->begin_suppress_tokens + (o->begin_suppress_tokens ? o->n_begin_suppress : 0));
-        if (!s->masks_valid || sup != s->sup_cached || bsup != s->bsup_cached) {
+        if (!s->masks_valid || sup != s->sup_cached || bsup != s->bsup_cached || no_ts != s->no_ts_cached) {
             std::vector<float> ms(m->Vpad, 0.f), mb(m->Vpad, 0.f);
+            if (no_ts >= 0 && no_ts < m->cfg.dims.vocab) ms[no_ts] = mb[no_ts] = -INFINITY;  // <|notimestamps|> is never emitted under the timestamp rules
+            s->no_ts_cached = no_ts;
             for (int32_t id : sup)
                 if (id >= 0 && id < m->cfg.dims.vocab) ms[id] = mb[id] = -INFINITY;
             for (int32_t id : bsup)
@@ -1316,18 +1351,20 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
         ip.B = v.nb;
         ip.tok_rows = s->lanes.size() == 1 ? s->tok_rows.as<int>() : nullptr;
         ip.pos_rows = s->pos_rows.as<int>();
+        ip.ts_state = rp ? s->ts_state.as<TsState>() + v.b0 : nullptr;
+        ip.rules = rules;
         launch_init_tokens(ip, v.st);
         // prefill (whisper.mojo:195, start_pos=0): the q_len = n_prompt causal block equals n_prompt single-token steps
         static const bool seq_prefill = wm_env("WM_SEQ_PREFILL") != nullptr;  // A/B: one pass per prompt position
         if (!seq_prefill && s->lanes.size() == 1 && o->n_prompt > 1 && o->n_prompt <= wm_state::PREFILL_MAX) {
-            decode_core(m, s, v, true, false, s->mask_begin.as<float>(), o->n_prompt);  // init_tokens filled tok_rows / pos_rows
+            decode_core(m, s, v, true, false, s->mask_begin.as<float>(), o->n_prompt, true, rp);  // init_tokens filled tok_rows / pos_rows
         } else {
             for (int i = 0; i < o->n_prompt; ++i) {
                 launch_set_step(v.ctl, i, 1, s->pos.as<int>() + v.b0, i, s->tok.as<int>() + v.b0, o->prompt[i], v.nb, v.st);
-                decode_core(m, s, v, i == o->n_prompt - 1, false, s->mask_begin.as<float>());
+                decode_core(m, s, v, i == o->n_prompt - 1, false, s->mask_begin.as<float>(), 1, true, rp);
             }
         }
-        launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot), v.st);  // :198-203
+        launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, false, false, rp), v.st);  // :198-203
         trace_mark(v.st, "state %p lane %d prefill end", (void*)s, v.b0);
         // incremental steps: start_pos = current_len - 1 (reference, :217) or current_len (HF)
         launch_set_step(v.ctl, o->n_prompt, 1, s->pos.as<int>() + v.b0, first_pos, nullptr, 0, v.nb, v.st);
@@ -1343,8 +1380,8 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
             }
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(v.st, hipStreamCaptureModeThreadLocal));
-            decode_core(m, s, v, true, false, s->mask_steady.as<float>(), 1, false);
-            launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, true, true), v.st);
+            decode_core(m, s, v, true, false, s->mask_steady.as<float>(), 1, false, rp);
+            launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, true, true, rp), v.st);
             HIPCHK(hipStreamEndCapture(v.st, &g));
             hipError_t ge = hipSuccess;
             for (int k = 0; k < wm_state::Lane::NEXEC && ge == hipSuccess; ++k) ge = hipGraphInstantiate(&ln.graph[k], g, nullptr, nullptr, 0);
@@ -1355,6 +1392,7 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
     s->graphs_valid = !no_graph;
     s->graph_eot = o->eot;
     s->graph_ignore = o->ignore_eot;
+    s->graph_rules = rules;
     if (trace_phase) {
         for (auto& ln : s->lanes) (void)hipStreamSynchronize(ln.st);
         fprintf(stderr, "[wm] encoder wait + prefill (+graph capture if any): %.3f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count() * 1e3);
@@ -1386,8 +1424,8 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
                 }
             } else {
                 const DecView v{ln.b0, ln.nb, ln.st, ln.ctl};
-                decode_core(m, s, v, true, false, s->mask_steady.as<float>(), 1, false);
-                launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, true, true), v.st);
+                decode_core(m, s, v, true, false, s->mask_steady.as<float>(), 1, false, rp);
+                launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, true, true, rp), v.st);
             }
         }
     }
@@ -1414,6 +1452,11 @@ static int check_opts(wm_model* m, const wm_decode_opts* o, int B) {
     if (o->n_suppress < 0 || o->n_begin_suppress < 0 || (o->n_suppress > 0 && !o->suppress_tokens) || (o->n_begin_suppress > 0 && !o->begin_suppress_tokens))
         return fail(WM_E_ARG, "bad suppress-token lists");
     const wm_dims& c = m->cfg.dims;
+    if (o->timestamp_begin > 0) {
+        if (o->timestamp_begin >= c.vocab) return fail(WM_E_ARG, "timestamp_begin %d is not a vocabulary id", o->timestamp_begin);
+        if (o->no_timestamps_token >= c.vocab) return fail(WM_E_ARG, "no_timestamps_token out of range");
+        if (o->eot < 0 || o->eot > o->timestamp_begin) return fail(WM_E_ARG, "timestamp rules need 0 <= eot <= timestamp_begin (eot is the processor's eos id)");
+    }
     const int total = o->n_prompt + 1 + o->max_loop;
     if (total > c.n_text_ctx + 1 || total > OUT_STRIDE_MAX)
         return fail(WM_E_ARG, "n_prompt + 1 + max_loop = %d exceeds the decoder context %d", total, c.n_text_ctx);

@@ -43,26 +43,6 @@ template <> __device__ __forceinline__ Frag<f16> load_frag<f16>(const f16* p) {
     return f;
 }
 
-// the same fragment from a read-once stream: non-temporal, so it does not push re-used lines (the decoder's layer weights)
-// out of L2 / the Infinity Cache
-template <typename T> __device__ __forceinline__ Frag<T> load_frag_nt(const T* p);
-template <> __device__ __forceinline__ Frag<float> load_frag_nt<float>(const float* p) {
-    Frag<float> f;
-    f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)), b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
-    f.v = f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    return f;
-}
-template <> __device__ __forceinline__ Frag<bf16> load_frag_nt<bf16>(const bf16* p) {
-    Frag<bf16> f;
-    f.v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
-    return f;
-}
-template <> __device__ __forceinline__ Frag<f16> load_frag_nt<f16>(const f16* p) {
-    Frag<f16> f;
-    f.v = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(p));
-    return f;
-}
-
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
 
 // fragment from 8 fp32 values (activations normalised on the fly)

@@ -63,6 +63,45 @@ void launch_layernorm_rows(const float* x, const float* gamma, const float* beta
 template <typename T> void launch_flash_attn_enc(const void* qkv, void* out, int B, int H, int n_ctx, float scale, hipStream_t st);
 
 // ---- decoder ------------------------------------------------------------------------------------------------
+// Timestamp rules of the fused argmax (semantics of HF's WhisperTimeStampLogitsProcessor, absent from the
+// reference).  Per utterance: what the rules need of the history, and the id ranges the NEXT argmax may choose from — written
+// by stage 2 of one step (argmax_step), read by stage 1 of the next (dec_logits).
+struct TsState {
+    int n_gen;    // ids generated so far (after the prompt)
+    int last_ts;  // the last one was a timestamp
+    int pen_ts;   // the one before was a timestamp (or there is none)
+    int t_last;   // the latest timestamp id emitted, -1 = none
+    int text_lo, text_hi;  // admissible "text" ids (everything below timestamp_begin): [text_lo, text_hi)
+    int ts_lo, ts_hi;      // admissible timestamp ids: [ts_lo, ts_hi)
+};
+struct TsRules {
+    int tb;        // timestamp_begin: first timestamp id (<|0.00|>); <= 0 = rules off
+    int eos;       // ids below it are "normal text" (masked after the first timestamp of a pair)
+    int max_init;  // max_initial_timestamp_index, < 0 = none
+    int vocab;
+};
+__host__ __device__ inline void ts_next_ranges(TsState& st, const TsRules& r) {  // ranges for the next argmax from the history
+    st.text_lo = 0;
+    st.text_hi = r.tb;
+    st.ts_lo = r.tb;
+    st.ts_hi = r.vocab;
+    if (st.n_gen == 0) {  // the first id is a timestamp, at most <|max_init * 0.02|>
+        st.text_hi = 0;
+        if (r.max_init >= 0 && r.tb + r.max_init + 1 < st.ts_hi) st.ts_hi = r.tb + r.max_init + 1;
+        return;
+    }
+    if (st.last_ts) {
+        if (st.pen_ts)
+            st.ts_hi = st.ts_lo;  // two in a row: the next one is not a timestamp
+        else
+            st.text_lo = r.eos;  // first of a pair: no normal text
+    }
+    if (st.t_last >= 0) {  // never decrease; do not re-emit a closed pair's value
+        const int ts_end = (st.last_ts && !st.pen_ts) ? st.t_last : st.t_last + 1;
+        if (ts_end > st.ts_lo) st.ts_lo = ts_end;
+    }
+}
+
 struct DecLinearParams {
     const float* x;  // [B][ldx] fp32 activations
     int ldx;
@@ -89,6 +128,14 @@ struct DecLinearParams {
     int* amax_idx;
     int amax_stride;
     const float* amax_mask;  // [N] additive mask (0 / -inf) applied to the argmax candidates only, or null
+    // timestamp rules (null = off): candidates are split into text ids and timestamp ids by the utterance's TsState ranges; the
+    // workgroups that cover ids >= ts_begin also emit the best admissible timestamp and (max, sum exp) of the admissible ones
+    const TsState* ts_state;  // [B]
+    int ts_begin;
+    float* ts_val;  // [B][amax_stride] like amax_val; written for parts >= ts_begin / (ids per part) only
+    int* ts_idx;
+    float* ts_m;
+    float* ts_s;
     long long* ts;  // developer timeline (dec_logits only)
     int ts_id;
 };
@@ -96,6 +143,7 @@ template <typename TW> void launch_dec_linear(const DecLinearParams& p, hipStrea
 bool dec_linear_supports_k(int K);  // K/32 k-steps must split into NW <= 16 waves x KPW <= 4 steps (checked at model load)
 template <typename TW> void launch_dec_logits(const DecLinearParams& p, hipStream_t st);
 int dec_logits_parts(int N);  // fused-argmax partials per utterance that launch_dec_logits writes (amax_stride must cover them)
+int dec_logits_ids_per_part(int N);  // vocabulary ids one part covers
 
 struct AttnDecParams {
     const float* q;  // [B][d] fp32
@@ -146,6 +194,14 @@ struct ArgmaxParams {
     const float* emb_pos;
     float* emb_out;
     int d, max_pos;
+    // timestamp rules (ts_state null = off): pval / pidx then hold the best admissible TEXT id of each part, ts_* the timestamp side
+    TsState* ts_state;
+    TsRules rules;
+    const float* ts_val;
+    const int* ts_idx;
+    const float* ts_m;
+    const float* ts_s;
+    int ts_part0;  // first part that covers timestamp ids
 };
 void launch_argmax_step(const ArgmaxParams& p, hipStream_t st);
 struct InitTokensParams {
@@ -158,6 +214,8 @@ struct InitTokensParams {
     int prompt[16];
     int* tok_rows;  // non-null: also fill the prefill's position-major token / position rows [n_prompt][B]
     int* pos_rows;
+    TsState* ts_state;  // non-null: start state of the timestamp rules
+    TsRules rules;
 };
 void launch_init_tokens(const InitTokensParams& p, hipStream_t st);
 void launch_set_step(StepCtl* ctl, int len, int set_len, int* pos, int pos_value, int* tok, int tok_value, int B,

@@ -183,22 +183,27 @@ class Whisper:
         except Exception:
             pass
 
-    def _opts(self, prompt, eot, max_loop, ignore_eot, suppress_tokens=(), begin_suppress_tokens=()):
+    def _opts(self, prompt, eot, max_loop, ignore_eot, suppress_tokens=(), begin_suppress_tokens=(), timestamps=None):
+        """timestamps: None (the reference: raw argmax) or (timestamp_begin, no_timestamps_id, max_initial_timestamp_index | None)
+        — HF's WhisperTimeStampLogitsProcessor inside the fused argmax."""
         p = np.asarray(prompt, np.int32)
         sup = np.asarray(list(suppress_tokens), np.int32)
         bsup = np.asarray(list(begin_suppress_tokens), np.int32)
+        tb, no_ts, max_init = (0, -1, -1) if timestamps is None else (int(timestamps[0]), int(timestamps[1]),
+                                                                      -1 if timestamps[2] is None else int(timestamps[2]))
         opts = _lib.WmDecodeOpts(_ip(p), len(p), eot, max_loop, self.pos_mode, int(ignore_eot),
-                                 _ip(sup) if len(sup) else None, len(sup), _ip(bsup) if len(bsup) else None, len(bsup))
+                                 _ip(sup) if len(sup) else None, len(sup), _ip(bsup) if len(bsup) else None, len(bsup),
+                                 tb, no_ts, max_init)
         return opts, (p, sup, bsup)
 
     def transcribe_batch(self, mel, prompt: Sequence[int] = PROMPT, eot: int = EOT, max_loop: int = MAX_LOOP,
                          ignore_eot: bool = False, suppress_tokens: Sequence[int] = (),
-                         begin_suppress_tokens: Sequence[int] = ()) -> List[List[int]]:
+                         begin_suppress_tokens: Sequence[int] = (), timestamps=None) -> List[List[int]]:
         """Batched Whisper.transcribe: one List[int] per utterance = prompt + generated ids (+ eot when hit)."""
         if self._h is None:
             raise _lib.WhisperMiError("model not loaded")
         ptr, on_dev, B, keep = _mel_arg(mel, self.config)
-        opts, keep2 = self._opts(prompt, eot, max_loop, ignore_eot, suppress_tokens, begin_suppress_tokens)
+        opts, keep2 = self._opts(prompt, eot, max_loop, ignore_eot, suppress_tokens, begin_suppress_tokens, timestamps)
         p = keep2[0]
         total = len(p) + 1 + max_loop
         toks = np.zeros((B, total), np.int32)
@@ -208,14 +213,15 @@ class Whisper:
         return [toks[b, :n[b]].tolist() for b in range(B)]
 
     def transcribe_submit(self, mel, slot: int = 0, prompt: Sequence[int] = PROMPT, eot: int = EOT, max_loop: int = MAX_LOOP,
-                          ignore_eot: bool = False):
+                          ignore_eot: bool = False, suppress_tokens: Sequence[int] = (), begin_suppress_tokens: Sequence[int] = (),
+                          timestamps=None):
         """Pipelined form (wm_transcribe_submit): enqueue encoder + greedy loop for this batch on pipeline slot 0..7 and
         return at once; `transcribe_wait(slot)` collects the ids.  Submitting batch i+1 before waiting for batch i lets
         its encoder overlap batch i's decode."""
         if self._h is None:
             raise _lib.WhisperMiError("model not loaded")
         ptr, on_dev, B, keep = _mel_arg(mel, self.config)
-        opts, keep2 = self._opts(prompt, eot, max_loop, ignore_eot)
+        opts, keep2 = self._opts(prompt, eot, max_loop, ignore_eot, suppress_tokens, begin_suppress_tokens, timestamps)
         p = keep2[0]
         _lib.check(_lib.lib().wm_transcribe_submit(self._h, slot, ptr, on_dev, B, C.byref(opts)))
         self._pending = getattr(self, "_pending", {})
