@@ -134,6 +134,12 @@ public:
         prompt_ = prompt;
         eot_ = eot;
     }
+    // timestamp rules of HF generate (the reference has none): timestamp_begin <= 0 switches them off
+    void set_timestamps(int timestamp_begin, int no_timestamps_token, int max_initial_timestamp_index) {
+        ts_begin_ = timestamp_begin;
+        no_ts_ = no_timestamps_token;
+        max_init_ = max_initial_timestamp_index;
+    }
     const WhisperConfig& config() const { return cfg_; }
     wm_model* handle() const { return model_; }
 
@@ -150,6 +156,9 @@ private:
         o.max_loop = max_loop;
         o.pos_mode = WM_POS_REF;  // start_pos = current_len - 1 (whisper.mojo:217)
         o.ignore_eot = ignore_eot ? 1 : 0;
+        o.timestamp_begin = ts_begin_;
+        o.no_timestamps_token = no_ts_;
+        o.max_initial_timestamp_index = max_init_;
         return o;
     }
     static std::vector<std::vector<int>> unpack(const std::vector<int32_t>& toks, const std::vector<int32_t>& n, int B, int stride) {
@@ -160,6 +169,7 @@ private:
     WhisperConfig cfg_;
     std::vector<int32_t> prompt_{PROMPT, PROMPT + 4};
     int32_t eot_ = EOT;
+    int ts_begin_ = 0, no_ts_ = -1, max_init_ = -1;
     wm_config wcfg_{};
     int device_ = 0;
     wm_model* model_ = nullptr;
