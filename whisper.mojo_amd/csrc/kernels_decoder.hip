@@ -53,8 +53,19 @@ void launch_dec_embed(const float* tok_emb, const float* pos_emb, const int* tok
 //   * computed as outᵀ (A-operand = weight fragment): a lane owns 4 consecutive columns of one utterance; the NW
 //     K-partials meet in LDS and wave 0 finishes (bias / GELU / residual / KV-cache append), with its epilogue operands
 //     requested before anything else so they ride the same round trip.
-template <typename TW, int KPW, bool LN, int NT>
+// dtype-tagged store of one fp32 value / four fp32 values (out_dtype: 0 fp32, 1 bf16, 2 f16)
+__device__ __forceinline__ void store_as(void* base, size_t idx, float v, int dt) {
+    if (dt == 0)
+        ((float*)base)[idx] = v;
+    else if (dt == 1)
+        ((bf16*)base)[idx] = (bf16)v;
+    else
+        ((f16*)base)[idx] = (f16)v;
+}
+
+template <typename TW, int KPW, bool LN, int NT, bool XT = false>
 __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
+    static_assert(!(LN && XT), "the LayerNorm prologue reads the fp32 residual stream");
     // dynamic LDS, sized by the launcher for the NW waves actually used: [NW][NT][64] f32x4 K-partials, then [NW][16][2]
     // LayerNorm statistics (24.6 + 1.5 KB for the 12-wave QKV / fc1 launches: fits beside two 64-KB GEMM workgroups)
     extern __shared__ __attribute__((aligned(16))) unsigned char dl_smem[];
@@ -73,6 +84,7 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
         wp[t] = (const TW*)p.W + (size_t)wrow * p.K + g * 8;
     }
     const float* xp = p.x + (size_t)xrow * p.ldx + g * 8;
+    const TW* xpt = (const TW*)p.x + (size_t)xrow * p.ldx + g * 8;  // XT: the same row in operand dtype
     // epilogue operands (wave t finishes column tile t)
     const int eb = b0 + r16, en = n0 + (w < NT ? w : 0) * 16 + g * 4;
     // a second column tile that starts past the (16-padded) width does not exist: storing it would land in the next row
@@ -89,14 +101,19 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
         if (p.kcache) cache_row = p.ctl->len;
     }
     Frag<TW> wf[NT][KPW];
-    f32x4 xa[KPW][2], gb[LN ? KPW : 1][4];
+    Frag<TW> xft[XT ? KPW : 1];
+    f32x4 xa[XT ? 1 : KPW][2], gb[LN ? KPW : 1][4];
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
         const int k = (w + nw * i) * 32;
 #pragma unroll
         for (int t = 0; t < NT; ++t) wf[t][i] = load_frag<TW>(wp[t] + k);
-        xa[i][0] = *reinterpret_cast<const f32x4*>(xp + k);
-        xa[i][1] = *reinterpret_cast<const f32x4*>(xp + k + 4);
+        if constexpr (XT) {
+            xft[i] = load_frag<TW>(xpt + k);
+        } else {
+            xa[i][0] = *reinterpret_cast<const f32x4*>(xp + k);
+            xa[i][1] = *reinterpret_cast<const f32x4*>(xp + k + 4);
+        }
         if (LN) {
             gb[i][0] = *reinterpret_cast<const f32x4*>(p.ln_g + k + g * 8);
             gb[i][1] = *reinterpret_cast<const f32x4*>(p.ln_g + k + g * 8 + 4);
@@ -105,7 +122,7 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
         }
     }
     float mean = 0.f, rstd = 1.f;
-    if (LN) {
+    if constexpr (LN) {
         float sm = 0.f, sq = 0.f;
 #pragma unroll
         for (int i = 0; i < KPW; ++i)
@@ -141,20 +158,25 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
-        float xv[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            xv[j] = xa[i][0][j];
-            xv[4 + j] = xa[i][1][j];
-        }
-        if (LN) {
+        Frag<TW> xf;
+        if constexpr (XT) {
+            xf = xft[i];
+        } else {
+            float xv[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                xv[j] = (xv[j] - mean) * rstd * gb[i][0][j] + gb[i][2][j];
-                xv[4 + j] = (xv[4 + j] - mean) * rstd * gb[i][1][j] + gb[i][3][j];
+                xv[j] = xa[i][0][j];
+                xv[4 + j] = xa[i][1][j];
             }
+            if (LN) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xv[j] = (xv[j] - mean) * rstd * gb[i][0][j] + gb[i][2][j];
+                    xv[4 + j] = (xv[4 + j] - mean) * rstd * gb[i][1][j] + gb[i][3][j];
+                }
+            }
+            xf = make_frag<TW>(xv);
         }
-        const Frag<TW> xf = make_frag<TW>(xv);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = mma32(wf[t][i], xf, acc[t]);
     }
@@ -186,6 +208,10 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
                 f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
                 *reinterpret_cast<f16x4*>((f16*)basep + off) = o;
             }
+        } else if (p.out_is_t && sizeof(TW) == 2) {
+            typedef __attribute__((ext_vector_type(4))) TW t4;
+            const t4 o = {from_f32<TW>(v[0]), from_f32<TW>(v[1]), from_f32<TW>(v[2]), from_f32<TW>(v[3])};
+            *reinterpret_cast<t4*>((TW*)p.out + (size_t)eb * p.ldo + en) = o;
         } else {
             *reinterpret_cast<f32x4*>(p.out + (size_t)eb * p.ldo + en) = v;
         }
@@ -202,6 +228,11 @@ template <typename TW, int KPW> static void launch_dec_linear_t(const DecLinearP
             hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, true, 2>), grid, block, smem(2), st, p);
         else
             hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, true, 1>), grid, block, smem(1), st, p);
+    } else if (sizeof(TW) == 2 && p.x_is_t) {  // activations already in operand dtype (attention output, MLP hidden)
+        if (wide)
+            hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, false, 2, true>), grid, block, smem(2), st, p);
+        else
+            hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, false, 1, true>), grid, block, smem(1), st, p);
     } else {
         if (wide)
             hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, false, 2>), grid, block, smem(2), st, p);
@@ -685,11 +716,15 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecParams p) {
                 for (int e = 0; e < EPL; ++e) o[e] += wgt * s_red[tt * EPL + e];
             }
             const size_t orow = (size_t)b + (size_t)t * qstride;
-            float* po = p.direct_out ? p.direct_out + orow * p.d + h * 64 + e0
-                                     : p.part_o + (orow * p.nsplit + split) * p.d + h * 64 + e0;
-            const float norm = p.direct_out ? 1.0f / L : 1.0f;
+            if (p.direct_out) {
+                const float norm = 1.0f / L;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) po[e] = o[e] * norm;
+                for (int e = 0; e < EPL; ++e) store_as(p.direct_out, orow * p.d + h * 64 + e0 + e, o[e] * norm, p.out_dtype);
+            } else {
+                float* po = p.part_o + (orow * p.nsplit + split) * p.d + h * 64 + e0;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) po[e] = o[e];
+            }
             if (!p.direct_out && (c % LPH) == 0) {
                 float* pml = p.part_ml + ((orow * p.nsplit + split) * p.H + h) * 2;
                 pml[0] = M;
@@ -745,7 +780,7 @@ template void launch_attn_decode<f16>(const AttnDecParams&, hipStream_t);
 // One wave per (utterance, head): lane s owns chunk s's (m, l) — one exp per chunk, not per element — and the
 // weights reach the 64 output lanes by wave broadcast.  nsplit <= 64.
 __global__ void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                    float* __restrict__ out, int nsplit, int H, int d, long long* ts, int ts_id) {
+                                    void* __restrict__ out, int out_dtype, int nsplit, int H, int d, long long* ts, int ts_id) {
     const int b = blockIdx.x, lane = threadIdx.x & 63, h = threadIdx.x >> 6;
     if (ts && b == 0 && threadIdx.x == 0) ts_put(ts, ts_id, 1);
     float m = -1e30f, l = 0.f;
@@ -768,11 +803,11 @@ __global__ void attn_combine_kernel(const float* __restrict__ part_o, const floa
         for (int j = 0; j < 8; ++j) o += __shfl(wgt, s + j, 64) * v[j];
     }
     for (; s < nsplit; ++s) o += __shfl(wgt, s, 64) * po[(size_t)s * d];
-    out[(size_t)b * d + h * 64 + lane] = o * (1.0f / L);
+    store_as(out, (size_t)b * d + h * 64 + lane, o * (1.0f / L), out_dtype);
 }
-void launch_attn_combine(const float* part_o, const float* part_ml, float* out, int B, int nsplit, int H, int d,
+void launch_attn_combine(const float* part_o, const float* part_ml, void* out, int out_dtype, int B, int nsplit, int H, int d,
                          hipStream_t st, long long* ts, int ts_id) {
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(B), dim3(64 * H), 0, st, part_o, part_ml, out, nsplit, H, d, ts, ts_id);
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(B), dim3(64 * H), 0, st, part_o, part_ml, out, out_dtype, nsplit, H, d, ts, ts_id);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -1063,8 +1063,9 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
     const size_t self_b = (size_t)v.b0 * c.n_text_ctx * d;
     float* dx = s->dx.as<float>() + (size_t)v.b0 * d;
     float* dq = s->dq.as<float>() + (size_t)v.b0 * d;
-    float* dattn = s->dattn.as<float>() + (size_t)v.b0 * d;
-    float* dhid = s->dhid.as<float>() + (size_t)v.b0 * c.ffn;
+    // attention output / MLP hidden rows: operand dtype T (fp32 buffers, used at T's width)
+    float* dattn = (float*)off_bytes(s->dattn, (size_t)v.b0 * d * dt_size(T));
+    float* dhid = (float*)off_bytes(s->dhid, (size_t)v.b0 * c.ffn * dt_size(T));
     if (embed)  // (the greedy loop's steps get their input row from the previous step's argmax launch instead)
         launch_dec_embed(m->tok_emb_f.as<float>(), m->dec_pos.as<float>(), P > 1 ? s->tok_rows.as<int>() : s->tok.as<int>() + v.b0,
                      P > 1 ? s->pos_rows.as<int>() : s->pos.as<int>() + v.b0, dx, B, c.d_model, st);
@@ -1106,15 +1107,18 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
             a.nsplit = 1;
             a.scale = scale;
             a.direct_out = dattn;
+            a.out_dtype = T;
             a.H = c.n_heads;
             a.d = c.d_model;
             a.B = B;
             attn_decode_dispatch(KV, a, st);
         }
+        // the attention outputs and the MLP hidden rows are handed over in operand dtype T (what the next MFMA consumes)
         auto proj_residual = [&](const float* in, int K, const DevBuf& W, const DevBuf& bias) {  // x += in·Wᵀ + b
             DecLinearParams p{};
             p.x = in;
             p.ldx = K;
+            p.x_is_t = 1;
             p.W = W.p;
             p.N = c.d_model;
             p.K = K;
@@ -1146,7 +1150,7 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
         // (merging the chunk partials inside the projection's prologue was measured 14 us per layer SLOWER than this
         // 3 us launch: 96 workgroups each re-reading 295 KB of partials)
         launch_attn_combine(s->part_o.as<float>() + (size_t)v.b0 * s->nsplit * d, s->part_ml.as<float>() + (size_t)v.b0 * s->nsplit * c.n_heads * 2,
-                            dattn, B, s->nsplit, c.n_heads, c.d_model, st, (long long*)m->ts_buf.p, s->trace_id);
+                            dattn, T, B, s->nsplit, c.n_heads, c.d_model, st, (long long*)m->ts_buf.p, s->trace_id);
         proj_residual(dattn, c.d_model, w.co_w, w.co_b);
         {  // LN2 -> fc1 + GELU
             DecLinearParams p{};
@@ -1162,6 +1166,7 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
             p.act = 1;
             p.gelu_mode = m->cfg.gelu_mode;
             p.out = dhid;
+            p.out_is_t = 1;
             p.ldo = c.ffn;
             dec_linear_dispatch(T, p, st);
         }
@@ -1729,142 +1734,6 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
         HIPCHK(hipEventRecord(e1, st));
         HIPCHK(hipEventSynchronize(e1));
         (void)hipGraphExecDestroy(ge);
-#ifdef WM_DEV
-    } else if (which >= 20 && which < 40) {
-        // debug chains of the REAL decode-step launches (layer 0 shapes), 40 per graph
-        const wm_dims& c = m->cfg.dims;
-        const DecView v = whole_batch(m, s);
-        const int KVd = m->cfg.kv_dtype, Td = m->cfg.compute_dtype;
-        DecLayer& w0 = m->dec[0];
-        const size_t ks = dt_size(KVd), dd = c.d_model;
-        const size_t self_l = (size_t)s->B * c.n_text_ctx * dd;
-        void* sk = s->self_kv.p;
-        void* sv = off_bytes(s->self_kv, self_l * ks);
-        auto one = [&](int kind) {
-            DecLinearParams p{};
-            p.B = s->B;
-            switch (kind) {
-                case 20:  // LN1 + QKV + cache append
-                    p.x = s->dx.as<float>(); p.ldx = c.d_model; p.ln_g = w0.ln1_g.as<float>(); p.ln_b = w0.ln1_b.as<float>();
-                    p.W = w0.sqkv_w.p; p.N = 3 * c.d_model; p.K = c.d_model; p.bias = w0.sqkv_b.as<float>(); p.out = s->dq.as<float>();
-                    p.ldo = c.d_model; p.kcache = sk; p.vcache = sv; p.kv_batch_stride = (long)((size_t)c.n_text_ctx * dd);
-                    p.d_model = c.d_model; p.kv_dtype = KVd; p.ctl = v.ctl;
-                    dec_linear_dispatch(Td, p, st);
-                    break;
-                case 21: {  // self attention at the current length
-                    AttnDecParams a{};
-                    a.q = s->dq.as<float>(); a.K = sk; a.V = sv; a.batch_stride = (long)((size_t)c.n_text_ctx * dd); a.n_keys = -1;
-                    a.ctl = v.ctl; a.nsplit = 1; a.scale = 0.125f; a.direct_out = s->dattn.as<float>(); a.H = c.n_heads; a.d = c.d_model; a.B = s->B;
-                    attn_decode_dispatch(KVd, a, st);
-                    break;
-                }
-                case 22:  // o-proj + residual
-                    p.x = s->dattn.as<float>(); p.ldx = c.d_model; p.W = w0.so_w.p; p.N = c.d_model; p.K = c.d_model; p.bias = w0.so_b.as<float>();
-                    p.residual = s->dx.as<float>(); p.ldr = c.d_model; p.out = s->dx.as<float>(); p.ldo = c.d_model;
-                    dec_linear_dispatch(Td, p, st);
-                    break;
-                case 23:  // LNx + q
-                    p.x = s->dx.as<float>(); p.ldx = c.d_model; p.ln_g = w0.lnx_g.as<float>(); p.ln_b = w0.lnx_b.as<float>(); p.W = w0.cq_w.p;
-                    p.N = c.d_model; p.K = c.d_model; p.bias = w0.cq_b.as<float>(); p.out = s->dq.as<float>(); p.ldo = c.d_model;
-                    dec_linear_dispatch(Td, p, st);
-                    break;
-                case 24: launch_cross_attn(m, s, 0, v); break;
-                case 25: launch_attn_combine(s->part_o.as<float>(), s->part_ml.as<float>(), s->dattn.as<float>(), s->B, s->nsplit, c.n_heads, c.d_model, st); break;
-                case 26:  // LN2 + fc1 + gelu
-                    p.x = s->dx.as<float>(); p.ldx = c.d_model; p.ln_g = w0.ln2_g.as<float>(); p.ln_b = w0.ln2_b.as<float>(); p.W = w0.fc1_w.p;
-                    p.N = c.ffn; p.K = c.d_model; p.bias = w0.fc1_b.as<float>(); p.act = 1; p.gelu_mode = m->cfg.gelu_mode; p.out = s->dhid.as<float>(); p.ldo = c.ffn;
-                    dec_linear_dispatch(Td, p, st);
-                    break;
-                case 27:  // fc2 + residual
-                    p.x = s->dhid.as<float>(); p.ldx = c.ffn; p.W = w0.fc2_w.p; p.N = c.d_model; p.K = c.ffn; p.bias = w0.fc2_b.as<float>();
-                    p.residual = s->dx.as<float>(); p.ldr = c.d_model; p.out = s->dx.as<float>(); p.ldo = c.d_model;
-                    dec_linear_dispatch(Td, p, st);
-                    break;
-                case 28:  // final LN + logits + argmax partials
-                    p.x = s->dx.as<float>(); p.ldx = c.d_model; p.ln_g = m->dec_ln_g.as<float>(); p.ln_b = m->dec_ln_b.as<float>();
-                    p.W = Td == WM_F32 ? m->tok_emb_f.p : m->tok_emb_t.p; p.N = c.vocab; p.K = c.d_model; p.out = nullptr; p.ldo = m->Vpad;
-                    p.amax_val = s->amax_val.as<float>(); p.amax_idx = s->amax_idx.as<int>(); p.amax_stride = s->npart;
-                    DISPATCH_DT(Td, TT, launch_dec_logits<TT>(p, st));
-                    break;
-                case 29: launch_argmax_step(argmax_params(m, s, v, false, -1, 1), st); break;
-                default: break;
-            }
-        };
-        launch_set_step(v.ctl, 60, 1, nullptr, 0, nullptr, 0, s->B, st);  // a mid-run cache length
-        hipGraph_t g = nullptr;
-        hipGraphExec_t ge = nullptr;
-        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        for (int i = 0; i < 40; ++i) one(which);
-        HIPCHK(hipStreamEndCapture(st, &g));
-        HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(g);
-        HIPCHK(hipGraphLaunch(ge, st));
-        HIPCHK(hipEventRecord(e0, st));
-        for (int i = 0; i < reps; ++i) HIPCHK(hipGraphLaunch(ge, st));
-        HIPCHK(hipEventRecord(e1, st));
-        HIPCHK(hipEventSynchronize(e1));
-        (void)hipGraphExecDestroy(ge);
-        float ms40 = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms40, e0, e1));
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        *avg_us = ms40 * 1000.0f / (float)(reps * 40);
-        return 0;
-    } else if (which >= 10 && which < 20) {
-        // debug chains (developer experiments): 40-node graphs of small decode kernels, replayed `reps` times
-        const wm_dims& c = m->cfg.dims;
-        DecLayer& w0 = m->dec[0];
-        auto lin = [&](bool ln) {
-            DecLinearParams p{};
-            p.x = s->dattn.as<float>();
-            p.ldx = c.d_model;
-            if (ln) {
-                p.ln_g = w0.ln1_g.as<float>();
-                p.ln_b = w0.ln1_b.as<float>();
-            }
-            p.W = w0.so_w.p;
-            p.N = c.d_model;
-            p.K = c.d_model;
-            p.B = s->B;
-            p.bias = w0.so_b.as<float>();
-            p.out = s->dq.as<float>();
-            p.ldo = c.d_model;
-            dec_linear_dispatch(m->cfg.compute_dtype, p, st);
-        };
-        auto emb = [&]() { launch_dec_embed(m->tok_emb_f.as<float>(), m->dec_pos.as<float>(), s->tok.as<int>(), s->pos.as<int>(), s->dx.as<float>(), s->B, c.d_model, st); };
-        auto comb = [&]() { launch_attn_combine(s->part_o.as<float>(), s->part_ml.as<float>(), s->dattn.as<float>(), s->B, s->nsplit, c.n_heads, c.d_model, st); };
-        auto setk = [&]() { launch_set_step(s->ctl.as<StepCtl>() + 7, 0, 1, nullptr, 0, nullptr, 0, s->B, st); };
-        hipGraph_t g = nullptr;
-        hipGraphExec_t ge = nullptr;
-        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        for (int i = 0; i < 40; ++i) {
-            switch (which) {
-                case 10: emb(); break;
-                case 11: setk(); break;
-                case 12: comb(); break;
-                case 13: lin(false); break;
-                case 14: lin(true); break;
-                case 15: if (i % 3 == 0) emb(); else if (i % 3 == 1) comb(); else setk(); break;
-                case 16: if (i % 2 == 0) lin(true); else comb(); break;
-                default: setk(); break;
-            }
-        }
-        HIPCHK(hipStreamEndCapture(st, &g));
-        HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(g);
-        HIPCHK(hipGraphLaunch(ge, st));
-        HIPCHK(hipEventRecord(e0, st));
-        for (int i = 0; i < reps; ++i) HIPCHK(hipGraphLaunch(ge, st));
-        HIPCHK(hipEventRecord(e1, st));
-        HIPCHK(hipEventSynchronize(e1));
-        (void)hipGraphExecDestroy(ge);
-        float ms40 = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms40, e0, e1));
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        *avg_us = ms40 * 1000.0f / (float)(reps * 40);
-        return 0;
-#endif  // WM_DEV
     } else if (which == WM_KERNEL_ENCODER) {
         if (!s->last_mel) return fail(WM_E_STATE, "no mel was encoded into this state");
         WMCHK(run_encoder(m, s, s->last_mel, s->B, st));

@@ -105,6 +105,9 @@ __host__ __device__ inline void ts_next_ranges(TsState& st, const TsRules& r) { 
 struct DecLinearParams {
     const float* x;  // [B][ldx] fp32 activations
     int ldx;
+    int x_is_t;    // != 0 (no LayerNorm prologue): x holds operand-dtype elements (TW) written by the producer kernel — exactly the
+                   // values the MFMA fragment conversion would produce, so results are unchanged; half the bytes, no conversion
+    int out_is_t;  // != 0 (plain output, no residual / cache append): out is stored as TW for such a consumer
     const float* ln_g;  // LayerNorm prologue (null = none)
     const float* ln_b;
     const void* W;  // [N][K], operand dtype
@@ -159,13 +162,14 @@ struct AttnDecParams {
     float* part_o;      // [B][nsplit][d]
     float* part_ml;     // [B][nsplit][H][2]
     float* direct_out;  // non-null (nsplit must be 1): write the normalised output [B][d] here, skip the partials
+    int out_dtype;      // element type of direct_out: WM_F32 / WM_BF16 / WM_F16 (the operand dtype of the projection that reads it)
     int H, d, B;
     int rps;  // filled by the launcher
     long long* ts;  // developer timeline (null = off): see ts_put in kernels_decoder.hip
     int ts_id;
 };
 template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStream_t st);
-void launch_attn_combine(const float* part_o, const float* part_ml, float* out, int B, int nsplit, int H, int d,
+void launch_attn_combine(const float* part_o, const float* part_ml, void* out, int out_dtype, int B, int nsplit, int H, int d,
                          hipStream_t st, long long* ts = nullptr, int ts_id = 0);
 
 void launch_dec_embed(const float* tok_emb, const float* pos_emb, const int* tok, const int* pos, float* x, int B, int d,
