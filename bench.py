@@ -41,8 +41,9 @@ WORKLOADS = {
     "tiny_b64_f32": ("tiny", 64, "f32", "f32"),
     "tiny_b1_f32": ("tiny", 1, "f32", "f32"),
     "base_b64_f16": ("base", 64, "f16", "f16"),
+    "tiny_b128_bf16": ("tiny", 128, "bf16", "bf16"),  # two batches of 64 coalesced into one decode state
 }
-LADDER = ["tiny_b64_bf16_kv32", "tiny_b64_f32", "tiny_b1_f32"]
+LADDER = ["tiny_b64_bf16_kv32", "tiny_b64_f32", "tiny_b1_f32", "tiny_b128_bf16"]
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 DECODE_STEPS = 99      # + 1 token from the prefill = 100 generated ids per utterance
 NATURAL_LOOP = 195     # whisper.mojo:205
