@@ -19,8 +19,8 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, 
                "--warmup 0 --no-cpu-baseline` (tiny_b64_bf16). Units: counter value = KB.  gfx950 correction (MI355X_MICROARCH.md "
                "§HBM): FETCH_SIZE reports 1/2 of a wide coalesced 16 B/lane streaming read -> fetch_bytes = 2 * FETCH_SIZE * 1024; "
                "WRITE_SIZE is exact.  Reduced by tools/pmc_traffic.py.", "kernels": {}}
-alg = {"cross": float(sys.argv[4]), "logits": 51865 * 384 * 2 + 64 * 384 * 4 + 64 * 250 * 8}
-for key, pat, label in (("cross", "attn_decode_kernelIDF16bLi8ELb1ELb1E", "attn_decode_kernel<bf16,NT> (cross-attention, one layer, B=64)"),
+alg = {"cross": float(sys.argv[4]), "logits": 51865 * 384 * 2 + 64 * 384 * 4 + 64 * 250 * 8}  # embedding once + x + (value, index) partials
+for key, pat, label in (("cross", "attn_decode_kernelIDF16bLi8ELb1ELb1ELi4ELi1E", "attn_decode_kernel<bf16,NT> (cross-attention, one layer, B=64)"),  # the step kernel (NQ = 1), not the 4-position prefill variant
                         ("logits", "dec_logits_kernelIDF16b", "dec_logits_kernel<bf16> (B=64)")):
     fk = [k for k in fetch if pat in k]
     if not fk: continue
