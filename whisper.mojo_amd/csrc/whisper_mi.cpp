@@ -463,7 +463,7 @@ static int model_build(wm_model* m, const float* w) {
     WMCHK(upload(m->dec_ln_b, r.take(d), d, WM_F32));
     WMCHK(upload(m->cross_kv_w, ckv.data(), ckv.size(), T));
     WMCHK(upload(m->cross_kv_b, ckvb.data(), ckvb.size(), WM_F32));
-    if (trace_events_on() && strchr(wm_env("WM_TRACE_EVENTS"), '/')) WMCHK(m->ts_buf.alloc(((2u << 20) + 1) * 8, true));
+    if (const char* tr = wm_env("WM_TRACE_EVENTS"); tr && strchr(tr, '/')) WMCHK(m->ts_buf.alloc(((2u << 20) + 1) * 8, true));
     if (r.off != wm_synth_count(&c)) return fail(WM_E_SIZE, "internal: consumed %zu floats, expected %zu", r.off, wm_synth_count(&c));
     return 0;
 }
