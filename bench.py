@@ -235,7 +235,7 @@ class Bench:
 
             def _chain(i):
                 try:
-                    _lib.check(L.wm_bench_kernel(m._h, sts[i], _lib.KERNEL_DECODE_STEP, 100, C.byref(us4[i])))
+                    _lib.check(L.wm_bench_kernel(m._h, sts[i], _lib.KERNEL_DECODE_STEP_SHARED, 100, C.byref(us4[i])))
                 except Exception as e:  # noqa: BLE001
                     errs.append(e)
             th = [threading.Thread(target=_chain, args=(i,)) for i in range(4)]

@@ -159,7 +159,8 @@ int wm_op_conv1d_k3(float* out, const float* inp, const float* weight, const flo
 int wm_op_argmax(const float* t, int n, int32_t* idx);
 
 /* ---- measurement helpers (bench.py) ----------------------------------------------------------------------------- */
-enum { WM_KERNEL_CROSS_ATTN = 0, WM_KERNEL_DECODE_STEP = 1, WM_KERNEL_ENCODER = 2 };
+enum { WM_KERNEL_CROSS_ATTN = 0, WM_KERNEL_DECODE_STEP = 1, WM_KERNEL_ENCODER = 2,
+       WM_KERNEL_DECODE_STEP_SHARED = 3 /* the step as wm_transcribe_submit's passes run it: K/V stream at two workgroups per CU */ };
 /* Launches `reps` instances of the named kernel / stage on the library's stream between two HIP events and
  * returns the average duration in microseconds.  State must have been encoded (cross K/V present). */
 int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, float* avg_us);

@@ -19,7 +19,7 @@ SYMBOLS = [
     "wm_op_argmax", "wm_bench_kernel", "wm_bench_bytes", "wm_synth_weights", "wm_synth_mel_host",
 ]
 
-KERNEL_CROSS_ATTN, KERNEL_DECODE_STEP, KERNEL_ENCODER = 0, 1, 2
+KERNEL_CROSS_ATTN, KERNEL_DECODE_STEP, KERNEL_ENCODER, KERNEL_DECODE_STEP_SHARED = 0, 1, 2, 3
 
 
 class WmConfig(C.Structure):

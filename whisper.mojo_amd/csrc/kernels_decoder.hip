@@ -220,7 +220,8 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
 template <typename TW, int KPW> static void launch_dec_linear_t(const DecLinearParams& p, int nw, hipStream_t st) {
     // two column tiles per workgroup for the wide projections (QKV, fc1): half the workgroups, one activation
     // fragment (and one LayerNorm) feeding two MFMAs
-    const bool wide = p.N >= 1024 && nw >= 2;
+    static const int nt_force = wm_env("WM_LIN_NT") ? atoi(wm_env("WM_LIN_NT")) : 0;  // dev A/B
+    const bool wide = nt_force ? nt_force == 2 : (p.N >= 1024 && nw >= 2);
     const dim3 grid((p.N + (wide ? 31 : 15)) / (wide ? 32 : 16), (p.B + 15) / 16), block(nw * 64);
     auto smem = [&](int nt) { return (size_t)nw * nt * 64 * sizeof(f32x4) + (size_t)nw * 16 * 2 * sizeof(float); };
     if (p.ln_g) {
@@ -241,17 +242,28 @@ template <typename TW, int KPW> static void launch_dec_linear_t(const DecLinearP
     }
 }
 // K % 32 == 0 and (K/32) must factor as NW * KPW with NW <= 16, KPW <= 4 (true for every K = 128·j, j <= 16).
-static int dec_linear_waves(int K) {
+static int dec_linear_waves(int K, int elem_bytes = 2) {
     if (K <= 0 || (K & 31)) return 0;
     const int ksteps = K >> 5;
-    for (int c = 16; c >= 1; --c)
-        if (ksteps % c == 0 && ksteps / c <= 4) return c;
+    if (elem_bytes == 4) {  // fp32 operands (eight exact-fp32 MFMAs per k-step): one k-step per wave stays fastest (B = 1: 211 vs 223 us per step)
+        for (int c = 16; c >= 1; --c)
+            if (ksteps % c == 0 && ksteps / c <= 4) return c;
+        return 0;
+    }
+    // the FEWEST waves whose k-steps-per-wave stay <= 3 (else <= 4): measured on MI355X (round 2, tiny B = 64) 4 waves x 3 k-steps
+    // for K = 384 beat 12 waves x 1 (decode step 266 -> 257 us; pass alone 33.3 -> 32.4 ms) — a 256-thread workgroup is
+    // dispatched sooner, exchanges 4 instead of 12 partials, and fits beside a K/V-streaming kernel of another pass; 6 x 2
+    // (263 us), 3 x 4 (274 us) and 2 x 6 (363 us) lost
+    static const int kpw_max = wm_env("WM_LIN_KPW") ? atoi(wm_env("WM_LIN_KPW")) : 3;
+    for (int lim = kpw_max; lim <= 4; ++lim)
+        for (int c = 1; c <= 16; ++c)
+            if (ksteps % c == 0 && ksteps / c <= lim) return c;
     return 0;
 }
 bool dec_linear_supports_k(int K) { return dec_linear_waves(K) > 0; }
 template <typename TW> void launch_dec_linear(const DecLinearParams& p, hipStream_t st) {
     const int ksteps = p.K >> 5;
-    const int nw = dec_linear_waves(p.K);
+    const int nw = dec_linear_waves(p.K, (int)sizeof(TW));
     if (nw == 0) {  // never reached through the C-ABI (check_cfg / wm_op_matmul_nt pad K): refuse rather than drop k-steps
         fprintf(stderr, "[whispermi] dec_linear: K = %d cannot be split over the waves of a workgroup — launch skipped\n", p.K);
         return;
@@ -756,12 +768,16 @@ template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStrea
         return;
     }
     if (p.n_keys >= 0 && !nt_off) {  // the cross-attention K/V stream (1500 rows per utterance, read once per step)
+        // p.lds_pad: unused dynamic LDS that caps the workgroups per CU (160 KB / (20 KB static + pad)) — see AttnDecParams
+        static const int pad_env = wm_env("WM_ATTN_LDS_PAD") ? atoi(wm_env("WM_ATTN_LDS_PAD")) : -1;  // dev A/B override
+        const int lds_pad = pad_env >= 0 ? pad_env : p.lds_pad;
+        if (lds_pad > 40 * 1024) (void)ensure_dyn_lds(&attn_decode_kernel<TKV, LPH, FAST, true, 4>, lds_pad);
         if (u_cross == 8)
             hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 8>), grid, block, 0, st, q);
         else if (u_cross == 2)
             hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 2>), grid, block, 0, st, q);
         else
-            hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 4>), grid, block, 0, st, q);
+            hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 4>), grid, block, lds_pad, st, q);
     } else {
         // self-attention: 4 rows per lane per iteration (measured per 64-clip pass alone: U = 1 / 2 34.6 ms, U = 4 34.3 ms — the
         // serial iteration count matters as the cache grows to 104 rows).  WM_SELF_U=2 for A/B.

@@ -217,6 +217,8 @@ struct wm_state {
     int graph_eot = 0, graph_ignore = 0;
     bool graphs_valid = false;
     bool pending = false;   // a submitted pass has not been waited for yet
+    bool shares_chip = false;  // this state's passes run beside other passes (pipelined entry): K/V stream at two workgroups per CU
+    bool graph_shares = false;
     int trace_id = 1;       // slot + 1: tags this state's entries in the developer timeline
     int pend_total = 0;     // ids per utterance of the pending pass
     const float* last_mel = nullptr;  // device pointer of the last encoded batch (bench replays the encoder on it)
@@ -1040,6 +1042,7 @@ static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v,
     a.nq = (P == 4 && !no_mq) ? 4 : 0;  // the reference's 4-token prompt: one K/V sweep for the four positions
     a.ts = (long long*)m->ts_buf.p;
     a.ts_id = s->trace_id;
+    a.lds_pad = s->shares_chip ? 34 * 1024 : 0;
     attn_decode_dispatch(m->cfg.kv_dtype, a, v.st);
 }
 
@@ -1318,8 +1321,9 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
     rules.vocab = m->cfg.dims.vocab;
     const TsRules* rp = rules.tb > 0 ? &rules : nullptr;
     const int no_ts = rp ? o->no_timestamps_token : -1;
+    s->shares_chip = !allow_poll;  // the pipelined entry (wm_transcribe_submit): other passes are, or will be, in flight
     const bool recapture = !s->graphs_valid || s->graph_eot != o->eot || s->graph_ignore != o->ignore_eot ||
-                           memcmp(&s->graph_rules, &rules, sizeof rules) != 0;
+                           s->graph_shares != s->shares_chip || memcmp(&s->graph_rules, &rules, sizeof rules) != 0;
     const int first_pos = o->pos_mode == WM_POS_REF ? o->n_prompt - 1 : o->n_prompt;
     // logit masks (§8f rank 4): rebuilt only when the id lists change; always passed (all-zero = the reference's raw argmax)
     {
@@ -1398,6 +1402,7 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
     s->graph_eot = o->eot;
     s->graph_ignore = o->ignore_eot;
     s->graph_rules = rules;
+    s->graph_shares = s->shares_chip;
     if (trace_phase) {
         for (auto& ln : s->lanes) (void)hipStreamSynchronize(ln.st);
         fprintf(stderr, "[wm] encoder wait + prefill (+graph capture if any): %.3f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count() * 1e3);
@@ -1678,7 +1683,7 @@ extern "C" int wm_bench_bytes(wm_model* m, wm_state* s, int which, double* bytes
     if (which == WM_KERNEL_CROSS_ATTN) {
         // one layer: K and V rows of every utterance once + q in + partials out
         *bytes = B * 2.0 * c.n_audio_ctx * d * ks + B * d * 4 + B * s->nsplit * (d + 2 * H) * 4;
-    } else if (which == WM_KERNEL_DECODE_STEP) {
+    } else if (which == WM_KERNEL_DECODE_STEP || which == WM_KERNEL_DECODE_STEP_SHARED) {
         // every weight once per step, KV once per utterance, KV write; logits are NOT materialised
         // (fused argmax: only B x ceil(V/128) (value, index) partials are written and re-read)
         const double f = c.ffn, L = c.n_layers, V = c.vocab;
@@ -1710,7 +1715,8 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
         HIPCHK(hipEventRecord(e0, st));
         for (int i = 0; i < reps; ++i) launch_cross_attn(m, s, i % L, v);  // cycles the layers: 4 x 295 MB > 256 MB L3
         HIPCHK(hipEventRecord(e1, st));
-    } else if (which == WM_KERNEL_DECODE_STEP) {
+    } else if (which == WM_KERNEL_DECODE_STEP || which == WM_KERNEL_DECODE_STEP_SHARED) {
+        s->shares_chip = which == WM_KERNEL_DECODE_STEP_SHARED;  // the K/V stream as pipelined passes launch it
         // on the state's own decode stream, as the transcribe loop runs it: several states can be timed concurrently
         // from several host threads (bench.py: four chains in flight)
         const int len0 = std::max(s->host_len, 1);
@@ -1734,6 +1740,7 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
         HIPCHK(hipEventRecord(e1, st));
         HIPCHK(hipEventSynchronize(e1));
         (void)hipGraphExecDestroy(ge);
+        s->shares_chip = false;
     } else if (which == WM_KERNEL_ENCODER) {
         if (!s->last_mel) return fail(WM_E_STATE, "no mel was encoded into this state");
         WMCHK(run_encoder(m, s, s->last_mel, s->B, st));

@@ -165,6 +165,12 @@ struct AttnDecParams {
     int out_dtype;      // element type of direct_out: WM_F32 / WM_BF16 / WM_F16 (the operand dtype of the projection that reads it)
     int H, d, B;
     int rps;  // filled by the launcher
+    // cross-attention only: bytes of UNUSED dynamic LDS per workgroup.  34 KB (+ 20 KB static) admits two workgroups per CU
+    // instead of four and leaves 52 KB of LDS and half the register file free: when several passes share the chip
+    // (wm_transcribe_submit), the other passes' latency-bound launches then start beside this K/V stream instead of queueing
+    // behind it — measured four passes in flight, tiny B = 64: 19.6 -> 19.1 ms per pass, although the kernel alone is
+    // 1 us slower (26.3 vs 25.3 us).  0 for a pass that has the chip to itself.
+    int lds_pad;
     long long* ts;  // developer timeline (null = off): see ts_put in kernels_decoder.hip
     int ts_id;
 };
