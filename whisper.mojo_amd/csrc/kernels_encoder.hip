@@ -680,8 +680,8 @@ __device__ __forceinline__ f16x4 lds_tr16(const f16* p) {
     return __builtin_bit_cast(f16x4, v);
 }
 
-template <typename T, int NW, int QB>
-__global__ __launch_bounds__(NW * 64) void flash_attn_enc_v2_kernel(const T* __restrict__ qkv, T* __restrict__ out, int n_ctx,
+template <typename T, int NW, int QB, int WPS = 1>
+__global__ __launch_bounds__(NW * 64, WPS) void flash_attn_enc_v2_kernel(const T* __restrict__ qkv, T* __restrict__ out, int n_ctx,
                                                                     int d_model, float scale_log2e, int xcd_remap) {
     // 160-byte rows (40 dwords): with the hardware's lane groups (ds_read_b128: {0-3,12-15,20-27}, ...; ds_read_b64_tr:
     // 32 lanes = 8 rows x 32 B) the 16 fragment rows / 8 transposed rows of one access fall on disjoint banks.  (144-byte
@@ -855,7 +855,13 @@ void launch_flash_attn_enc(const void* qkv, void* out, int B, int H, int n_ctx, 
             const float sl = scale * 1.4426950408889634f;
             if (var == 1) {
                 dim3 grid((n_ctx + 127) / 128, H, B);
-                hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 8, 1>), grid, dim3(512), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, remap);
+                // WPS = 6 waves per SIMD = three 512-thread workgroups per CU: caps the kernel at 80 VGPRs (91 unconstrained, 7 of
+                // them spilled) — the third workgroup hides more of the per-tile barrier / LDS latency than the spills cost
+                static const bool wps1 = wm_env("WM_ATTN_WPS1") != nullptr;  // dev A/B: unconstrained registers, two workgroups per CU
+                if (wps1)
+                    hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 8, 1, 1>), grid, dim3(512), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, remap);
+                else
+                    hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 8, 1, 6>), grid, dim3(512), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, remap);
             } else if (var == 2) {
                 dim3 grid((n_ctx + 255) / 256, H, B);
                 hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 8, 2>), grid, dim3(512), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, remap);
