@@ -772,20 +772,28 @@ template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStrea
         static const int pad_env = wm_env("WM_ATTN_LDS_PAD") ? atoi(wm_env("WM_ATTN_LDS_PAD")) : -1;  // dev A/B override
         const int lds_pad = pad_env >= 0 ? pad_env : p.lds_pad;
         if (lds_pad > 40 * 1024) (void)ensure_dyn_lds(&attn_decode_kernel<TKV, LPH, FAST, true, 4>, lds_pad);
-        if (u_cross == 8)
+#ifdef WM_DEV
+        if (u_cross == 8) {
             hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 8>), grid, block, 0, st, q);
-        else if (u_cross == 2)
+            return;
+        } else if (u_cross == 2) {
             hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 2>), grid, block, 0, st, q);
-        else
-            hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 4>), grid, block, lds_pad, st, q);
+            return;
+        }
+#endif
+        (void)u_cross;
+        hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 4>), grid, block, lds_pad, st, q);
     } else {
         // self-attention: 4 rows per lane per iteration (measured per 64-clip pass alone: U = 1 / 2 34.6 ms, U = 4 34.3 ms — the
         // serial iteration count matters as the cache grows to 104 rows).  WM_SELF_U=2 for A/B.
+#ifdef WM_DEV
         static const int u_self = wm_env("WM_SELF_U") ? atoi(wm_env("WM_SELF_U")) : 4;
-        if (u_self == 2)
+        if (u_self == 2) {
             hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, false, 2>), grid, block, 0, st, q);
-        else
-            hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, false, 4>), grid, block, 0, st, q);
+            return;
+        }
+#endif
+        hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, false, 4>), grid, block, 0, st, q);
     }
 }
 template void launch_attn_decode<float>(const AttnDecParams&, hipStream_t);

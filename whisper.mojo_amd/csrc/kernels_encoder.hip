@@ -845,40 +845,41 @@ __global__ __launch_bounds__(NW * 64, WPS) void flash_attn_enc_v2_kernel(const T
 
 template <typename T>
 void launch_flash_attn_enc(const void* qkv, void* out, int B, int H, int n_ctx, float scale, hipStream_t st) {
-    static const bool v1 = wm_env("WM_ATTN_V1") != nullptr;
-    // measured (tiny, 8 utterances per pass, encoder ms per 64 clips): 8 waves x 1 q-block 9.73 | 4x1 9.75 | 4x2 10.13 | 8x2 10.31
-    static const int var = wm_env("WM_ATTN_VAR") ? atoi(wm_env("WM_ATTN_VAR")) : 1;
-    static const bool no_xcd = wm_env("WM_ATTN_NOXCD") != nullptr;
     if constexpr (sizeof(T) == 2) {
-        if (!v1) {
-            const int remap = (!no_xcd && (B * H) % 8 == 0) ? 1 : 0;
-            const float sl = scale * 1.4426950408889634f;
-            if (var == 1) {
-                dim3 grid((n_ctx + 127) / 128, H, B);
-                // WPS = 6 waves per SIMD = three 512-thread workgroups per CU: caps the kernel at 80 VGPRs (91 unconstrained, 7 of
-                // them spilled) — the third workgroup hides more of the per-tile barrier / LDS latency than the spills cost
-                static const bool wps1 = wm_env("WM_ATTN_WPS1") != nullptr;  // dev A/B: unconstrained registers, two workgroups per CU
-                if (wps1)
-                    hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 8, 1, 1>), grid, dim3(512), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, remap);
-                else
-                    hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 8, 1, 6>), grid, dim3(512), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, remap);
-            } else if (var == 2) {
-                dim3 grid((n_ctx + 255) / 256, H, B);
-                hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 8, 2>), grid, dim3(512), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, remap);
-            } else if (var == 3) {
-                dim3 grid((n_ctx + 63) / 64, H, B);
-                hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 4, 1>), grid, dim3(256), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, remap);
-            } else {
-                dim3 grid((n_ctx + 127) / 128, H, B);
-                hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 4, 2>), grid, dim3(256), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, remap);
-            }
+        // 16-bit operands: 8 waves x one 16-row query block (128 query rows per workgroup), three workgroups per CU
+        // (WPS = 6 waves per SIMD caps the kernel at 80 VGPRs — 91 unconstrained, 7 spilled: the third workgroup hides more of
+        // the per-tile barrier / LDS latency than the spills cost; 471 -> 447 us per launch at 64 clips).
+        // Measured alternatives (tiny, encoder ms per 64 clips at 8 utterances per pass): 8x1 9.73 | 4x1 9.75 | 4x2 10.13 | 8x2 10.31.
+        const int remap = (B * H) % 8 == 0 ? 1 : 0;
+        const float sl = scale * 1.4426950408889634f;
+#ifdef WM_DEV  // A/B variants of the developer build: WM_ATTN_V1 (generic kernel), WM_ATTN_VAR=2..4 (other tilings), WM_ATTN_WPS1, WM_ATTN_NOXCD
+        static const bool v1 = wm_env("WM_ATTN_V1") != nullptr;
+        static const int var = wm_env("WM_ATTN_VAR") ? atoi(wm_env("WM_ATTN_VAR")) : 1;
+        static const bool no_xcd = wm_env("WM_ATTN_NOXCD") != nullptr;
+        static const bool wps1 = wm_env("WM_ATTN_WPS1") != nullptr;
+        const int rm = no_xcd ? 0 : remap;
+        if (v1) {
+            hipLaunchKernelGGL((flash_attn_enc_kernel<T, true>), dim3((n_ctx + 63) / 64, H, B), dim3(256), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, scale);
             return;
         }
+        if (var == 2) {
+            hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 8, 2>), dim3((n_ctx + 255) / 256, H, B), dim3(512), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, rm);
+            return;
+        } else if (var == 3) {
+            hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 4, 1>), dim3((n_ctx + 63) / 64, H, B), dim3(256), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, rm);
+            return;
+        } else if (var == 4) {
+            hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 4, 2>), dim3((n_ctx + 127) / 128, H, B), dim3(256), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, rm);
+            return;
+        } else if (wps1 || no_xcd) {
+            hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 8, 1, 1>), dim3((n_ctx + 127) / 128, H, B), dim3(512), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, rm);
+            return;
+        }
+#endif
+        hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 8, 1, 6>), dim3((n_ctx + 127) / 128, H, B), dim3(512), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, remap);
+    } else {  // exact-fp32 operands: the generic kernel
+        hipLaunchKernelGGL((flash_attn_enc_kernel<T, false>), dim3((n_ctx + 63) / 64, H, B), dim3(256), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, scale);
     }
-    dim3 grid((n_ctx + 63) / 64, H, B);
-    constexpr bool FAST = sizeof(T) == 2;
-    hipLaunchKernelGGL((flash_attn_enc_kernel<T, FAST>), grid, dim3(256), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64,
-                       scale);
 }
 
 // ---- explicit instantiations --------------------------------------------------------------------------------
