@@ -36,6 +36,9 @@ typedef struct {
                           residual stream stay fp32 */
     int kv_dtype;      /* storage type of the self- and cross-attention K/V cache: WM_F32 or compute_dtype */
     int max_batch;     /* largest B any later call will pass (arena sizing) */
+    int decoder_fp32;  /* != 0: compute_dtype applies to the ENCODER only (conv stem, encoder blocks, cross-K/V projection); the
+                          decoder's weights and MFMA operands stay fp32 — BASELINE config 3 read literally ("bf16 encoder GEMMs").
+                          0 (a zero-filled tail): one dtype for both, as before */
 } wm_config;
 
 /* Replaces the literals in Whisper.transcribe (whisper.mojo:187-191 prompt, :206 eot, :205 loop bound). */

@@ -24,7 +24,7 @@ KERNEL_CROSS_ATTN, KERNEL_DECODE_STEP, KERNEL_ENCODER, KERNEL_DECODE_STEP_SHARED
 
 class WmConfig(C.Structure):
     _fields_ = [("dims", WmDims), ("gelu_mode", C.c_int), ("compute_dtype", C.c_int), ("kv_dtype", C.c_int),
-                ("max_batch", C.c_int)]
+                ("max_batch", C.c_int), ("decoder_fp32", C.c_int)]
 
 
 class WmDecodeOpts(C.Structure):

@@ -90,6 +90,7 @@ static void trace_dump() {
 }
 
 static size_t dt_size(int dt) { return dt == WM_F32 ? 4 : 2; }
+static int dec_dtype(const wm_config& c) { return c.decoder_fp32 ? WM_F32 : c.compute_dtype; }  // operand dtype of the decoder
 static inline uint16_t f32_to_bf16_host(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -294,6 +295,7 @@ static int check_cfg(const wm_config* c) {
     if (c->compute_dtype < 0 || c->compute_dtype > 2) return fail(WM_E_ARG, "bad compute_dtype");
     if (!(c->kv_dtype == WM_F32 || c->kv_dtype == c->compute_dtype))
         return fail(WM_E_ARG, "kv_dtype must be WM_F32 or equal compute_dtype");
+    if (c->decoder_fp32 != 0 && c->decoder_fp32 != 1) return fail(WM_E_ARG, "decoder_fp32 must be 0 or 1");
     if (c->max_batch <= 0) return fail(WM_E_ARG, "max_batch must be > 0");
     if (c->gelu_mode != 0 && c->gelu_mode != 1) return fail(WM_E_ARG, "bad gelu_mode");
     return 0;
@@ -379,7 +381,8 @@ extern "C" void wm_model_free(wm_model* m) {
 static int model_build(wm_model* m, const float* w) {
     const wm_dims& c = m->cfg.dims;
     const size_t d = c.d_model, f = c.ffn;
-    const int T = m->cfg.compute_dtype;
+    const int T = m->cfg.compute_dtype;  // encoder-side operands (incl. the cross-K/V projection of the encoder output)
+    const int TD = dec_dtype(m->cfg);    // decoder-side operands
     Reader r{w};
     m->Cp = (c.n_mels + 31) / 32 * 32;
     m->Vpad = (c.vocab + 15) / 16 * 16;
@@ -429,7 +432,7 @@ static int model_build(wm_model* m, const float* w) {
     {
         const float* te = r.take((size_t)c.vocab * d);
         WMCHK(upload(m->tok_emb_f, te, (size_t)c.vocab * d, WM_F32));
-        if (T != WM_F32) WMCHK(upload(m->tok_emb_t, te, (size_t)c.vocab * d, T));
+        if (TD != WM_F32) WMCHK(upload(m->tok_emb_t, te, (size_t)c.vocab * d, TD));
         WMCHK(upload(m->dec_pos, r.take((size_t)c.n_text_ctx * d), (size_t)c.n_text_ctx * d, WM_F32));
     }
     std::vector<float> ckv((size_t)c.n_layers * 2 * d * d), ckvb((size_t)c.n_layers * 2 * d, 0.f);
@@ -438,25 +441,25 @@ static int model_build(wm_model* m, const float* w) {
         DecLayer& l = m->dec[i];
         AttnW a = read_attn(r, d);
         pack_qkv(a);
-        WMCHK(upload(l.sqkv_w, qkv.data(), qkv.size(), T));
+        WMCHK(upload(l.sqkv_w, qkv.data(), qkv.size(), TD));
         WMCHK(upload(l.sqkv_b, qkvb.data(), qkvb.size(), WM_F32));
-        WMCHK(upload(l.so_w, a.o_w, d * d, T));
+        WMCHK(upload(l.so_w, a.o_w, d * d, TD));
         WMCHK(upload(l.so_b, a.o_b, d, WM_F32));
         WMCHK(upload(l.ln1_g, r.take(d), d, WM_F32));
         WMCHK(upload(l.ln1_b, r.take(d), d, WM_F32));
         AttnW x = read_attn(r, d);
-        WMCHK(upload(l.cq_w, x.q_w, d * d, T));
+        WMCHK(upload(l.cq_w, x.q_w, d * d, TD));
         WMCHK(upload(l.cq_b, x.q_b, d, WM_F32));
         memcpy(ckv.data() + (size_t)(2 * i) * d * d, x.k_w, d * d * 4);
         memcpy(ckv.data() + (size_t)(2 * i + 1) * d * d, x.v_w, d * d * 4);
         memcpy(ckvb.data() + (size_t)(2 * i + 1) * d, x.v_b, d * 4);
-        WMCHK(upload(l.co_w, x.o_w, d * d, T));
+        WMCHK(upload(l.co_w, x.o_w, d * d, TD));
         WMCHK(upload(l.co_b, x.o_b, d, WM_F32));
         WMCHK(upload(l.lnx_g, r.take(d), d, WM_F32));
         WMCHK(upload(l.lnx_b, r.take(d), d, WM_F32));
-        WMCHK(upload(l.fc1_w, r.take(f * d), f * d, T));
+        WMCHK(upload(l.fc1_w, r.take(f * d), f * d, TD));
         WMCHK(upload(l.fc1_b, r.take(f), f, WM_F32));
-        WMCHK(upload(l.fc2_w, r.take(d * f), d * f, T));
+        WMCHK(upload(l.fc2_w, r.take(d * f), d * f, TD));
         WMCHK(upload(l.fc2_b, r.take(d), d, WM_F32));
         WMCHK(upload(l.ln2_g, r.take(d), d, WM_F32));
         WMCHK(upload(l.ln2_b, r.take(d), d, WM_F32));
@@ -1055,7 +1058,7 @@ static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v,
 static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_logits, bool full_logits = false,
                         const float* mask = nullptr, int P = 1, bool embed = true, const TsRules* rules = nullptr) {
     const wm_dims& c = m->cfg.dims;
-    const int T = m->cfg.compute_dtype, KV = m->cfg.kv_dtype;
+    const int T = dec_dtype(m->cfg), KV = m->cfg.kv_dtype;  // T: the decoder's operand dtype
     const int B = v.nb * P;          // activation rows of this pass
     const int qB = P > 1 ? v.nb : 0;  // position-major row mapping on
     const size_t d = c.d_model, ks = dt_size(KV);
@@ -1679,7 +1682,7 @@ extern "C" int wm_bench_bytes(wm_model* m, wm_state* s, int which, double* bytes
     if (!state_is_live(s) || s->m != m) return fail(WM_E_ARG, "stale or foreign state handle");
     const wm_dims& c = m->cfg.dims;
     const double d = c.d_model, H = c.n_heads, B = s->B;
-    const double ks = dt_size(m->cfg.kv_dtype), ws = dt_size(m->cfg.compute_dtype);
+    const double ks = dt_size(m->cfg.kv_dtype), ws = dt_size(dec_dtype(m->cfg));
     if (which == WM_KERNEL_CROSS_ATTN) {
         // one layer: K and V rows of every utterance once + q in + partials out
         *bytes = B * 2.0 * c.n_audio_ctx * d * ks + B * d * 4 + B * s->nsplit * (d + 2 * H) * 4;
