@@ -10,6 +10,8 @@ from .config import WmDims
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # WM_USE_DEV_LIB=1 (developer tools only) selects the -DWM_DEV build with the A/B switches and debug chains
 LIB_PATH = os.path.join(_HERE, "csrc", "libwhispermi_dev.so" if os.environ.get("WM_USE_DEV_LIB") else "libwhispermi.so")
+if os.environ.get("WM_USE_DEV_LIB") and os.environ.get("WM_DEV_LIB_PATH"):  # a developer A/B build kept under another name
+    LIB_PATH = os.environ["WM_DEV_LIB_PATH"]
 
 # every symbol include/whisper_mi.h declares (tests/test_cabi_symbols.py checks the .so exports all of them)
 SYMBOLS = [

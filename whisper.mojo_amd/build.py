@@ -68,7 +68,7 @@ def stale(dev: bool = False) -> bool:
 
 def build(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
     lib = LIB_DEV if dev else LIB
-    flags = FLAGS + (["-DWM_DEV"] if dev else [])
+    flags = FLAGS + (["-DWM_DEV"] + os.environ.get("WM_DEV_HIPCC_FLAGS", "").split() if dev else [])  # extra -D switches for developer A/B builds
     digest = _lib_digest(flags)
     if not force and _stamp_ok(lib, digest):
         return lib

@@ -300,14 +300,24 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
     constexpr int PITCH = K + PAD;
     constexpr int KS = KD * 4;                         // k-steps of 32
     constexpr int CHK = sizeof(TW) == 2 ? KS : KS / 2;  // k-steps whose weight fragments are in flight together
+#ifndef WM_LOGITS_PRE
+#define WM_LOGITS_PRE 4
+#endif
+    constexpr int PRE = WM_LOGITS_PRE < CHK ? WM_LOGITS_PRE : CHK;  // k-steps of the first tile requested before the staging arithmetic
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     TW* xs = reinterpret_cast<TW*>(smem_raw);  // [NRB*16][PITCH]
-    __shared__ float s_av[8][NRB * 16];
-    __shared__ int s_ai[8][NRB * 16];
+    __shared__ float s_av[8 * 4][NRB * 16];  // [wave][lane group g][utterance row]: the 4 lane groups of a row meet in LDS, not by
+    __shared__ int s_ai[8 * 4][NRB * 16];    // cross-lane shuffles (two ds_bpermute round trips per row block on the kernel's tail)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int row0 = blockIdx.y * NRB * 16;
     if (p.ts && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ts_put(p.ts, p.ts_id, 2);
+#ifdef WM_DEV
+#define WM_LG_STAMP(k) do { if (p.dbg && (threadIdx.x & 63) == 0) p.dbg[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define WM_LG_STAMP(k) do { } while (0)
+#endif
+    WM_LG_STAMP(0);
     const int nrows = min(NRB * 16, p.B - row0);
     int n0[2];
     bool have[2];
@@ -321,10 +331,14 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
         wr = wr < p.N ? wr : p.N - 1;
         wp[nb] = (const TW*)p.W + (size_t)wr * K + g * 8;
     }
-    // Memory operations retire in issue order (vmcnt), so the activation rows are requested FIRST and the embedding
-    // rows right behind them: the LayerNorm staging below waits only for the (L2-resident) activations and runs while
-    // this wave's embedding rows are still streaming from HBM.
+    // a wave without a second tile re-requests its first one (same lines: L1 / L2 hits, no extra HBM traffic) so that the loads
+    // below are UNCONDITIONAL: with a branch around them hipcc's s_waitcnt bookkeeping can no longer count them and makes the
+    // LayerNorm staging wait for every embedding row (vmcnt(11) … vmcnt(0) in front of the statistics: 5 us of the kernel)
+    if (!have[1]) wp[1] = wp[0];
+    // The activation rows are requested first; the embedding rows once they are here (see below), so the LayerNorm staging
+    // runs while this wave's embedding rows stream from HBM.
     Frag<TW> wf[2][CHK];
+    float mk[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // additive argmax mask (0 / -inf) of this lane's columns
     __shared__ __attribute__((aligned(16))) float s_gb[2][K];  // LN gamma / beta, fetched ahead of the embedding rows too
     {  // LN + convert -> LDS.  thread t: row t>>3 (+64 per pass), eighth t&7 of the row, float4 index q + 8*i
         for (int rbase = 0; rbase < NRB * 16; rbase += 64) {
@@ -341,14 +355,22 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
                 f32x4 gbv = f32x4{0.f, 0.f, 0.f, 0.f};
                 const int gi = threadIdx.x;  // float4 index into [gamma | beta]
                 if (gi < K / 2) gbv = *reinterpret_cast<const f32x4*>((gi < K / 4 ? p.ln_g : p.ln_b - K) + 4 * gi);
+                if (p.amax_mask) {  // the argmax mask of this lane's 8 columns rides the same round trip (the epilogue used to fetch it)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-                    if (have[nb]) {
+                    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                        for (int i = 0; i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + i * 32);
-                    }
+                        for (int r = 0; r < 4; ++r) mk[nb][r] = p.amax_mask[min(n0[nb] + g * 4 + r, p.N - 1)];
+                }
                 if (gi < K / 2) *reinterpret_cast<f32x4*>(&s_gb[0][0] + 4 * gi) = gbv;
+                WM_LG_STAMP(5);
                 __syncthreads();
+                WM_LG_STAMP(6);
+                // The embedding rows are requested only now, when this workgroup's activation rows have arrived: issued together
+                // with them (round 1) the 40 MB burst of all 250 workgroups filled the memory pipeline first and the 98 KB of
+                // activations every workgroup needs — the same L2 lines for all of them — came back last: the LayerNorm staging
+                // ended 7.8 us after kernel entry, 1.7 us before the MFMAs did (in-kernel stamps, tools/logits_phases.py).
+#pragma unroll
+                for (int i = 0; i < PRE; ++i) wf[0][i] = load_frag<TW>(wp[0] + i * 32);
             }
             if (mine) {
                 float sm = 0.f, sq = 0.f;
@@ -380,7 +402,16 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
             }
         }
     }
+    WM_LG_STAMP(1);
     __syncthreads();
+    WM_LG_STAMP(2);
+    // the rest of the embedding rows, behind the staging arithmetic AND the barrier: a wave cannot issue past a vector load the
+    // memory pipeline has no room for, so with all 24 KB per wave requested up front the staging stood behind the loads' ISSUE
+    // for ~5 us (in-kernel stamps), and a barrier after the issue made every wave wait for the slowest issuer
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int i = (nb == 0 ? PRE : 0); i < CHK; ++i) wf[nb][i] = load_frag<TW>(wp[nb] + i * 32);
 
     f32x4 acc[2][NRB];
 #pragma unroll
@@ -414,6 +445,7 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
         body(std::integral_constant<int, 2>{});
     else if (have[0])
         body(std::integral_constant<int, 1>{});
+    WM_LG_STAMP(3);
     // acc[nb][rb][r] = logits[row0 + 16 rb + r16][n0[nb] + 4 g + r]
     if (p.out) {
 #pragma unroll
@@ -456,7 +488,7 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n = n0[nb] + g * 4 + r;
-                    const float v = acc[nb][rb][r] + (p.amax_mask ? p.amax_mask[min(n, p.N - 1)] : 0.f);  // 0 or -inf
+                    const float v = acc[nb][rb][r] + mk[nb][r];  // 0 or -inf
                     cand[nb][r] = v;
                     if (have[nb] && n < p.N && n >= t_lo && n < t_hi && v > bv) {  // n increases through the loop: strict '>' keeps the lowest index
                         bv = v;
@@ -503,26 +535,15 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
                     s_ts[w][rb * 16 + r16] = tsum;
                 }
             }
-#pragma unroll
-            for (int o = 16; o <= 32; o <<= 1) {
-                const float v2 = __shfl_xor(bv, o, 64);
-                const int i2 = __shfl_xor(bi, o, 64);
-                if (v2 > bv || (v2 == bv && i2 < bi)) {
-                    bv = v2;
-                    bi = i2;
-                }
-            }
-            if (g == 0) {
-                s_av[w][rb * 16 + r16] = bv;
-                s_ai[w][rb * 16 + r16] = bi;
-            }
+            s_av[w * 4 + g][rb * 16 + r16] = bv;
+            s_ai[w * 4 + g][rb * 16 + r16] = bi;
         }
         __syncthreads();
         if (threadIdx.x < NRB * 16 && (int)threadIdx.x < nrows) {
             float bv = s_av[0][threadIdx.x];
             int bi = s_ai[0][threadIdx.x];
 #pragma unroll
-            for (int k = 1; k < 8; ++k) {
+            for (int k = 1; k < 8 * 4; ++k) {
                 const float v2 = s_av[k][threadIdx.x];
                 const int i2 = s_ai[k][threadIdx.x];
                 if (v2 > bv || (v2 == bv && i2 < bi)) {
@@ -555,7 +576,9 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
             }
         }
     }
+    WM_LG_STAMP(4);
 }
+#undef WM_LG_STAMP
 // column tiles (of 16) per workgroup: the smallest count that covers the vocabulary with <= 256 workgroups, at most 16
 int dec_logits_tiles_per_wg(int N) {
     const int tiles = (N + 15) / 16;

@@ -1744,6 +1744,43 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
         HIPCHK(hipEventSynchronize(e1));
         (void)hipGraphExecDestroy(ge);
         s->shares_chip = false;
+#ifdef WM_DEV
+    } else if (which == 40) {  // developer: phase stamps of one logits launch (after a few warm ones), printed to stderr
+        const wm_dims& c = m->cfg.dims;
+        const int T = dec_dtype(m->cfg);
+        DevBuf dbg;
+        const int nwg = s->npart;
+        WMCHK(dbg.alloc((size_t)nwg * 8 * 8 * 8, true));
+        DecLinearParams p{};
+        p.x = s->dx.as<float>(); p.ldx = c.d_model; p.ln_g = m->dec_ln_g.as<float>(); p.ln_b = m->dec_ln_b.as<float>();
+        p.W = T == WM_F32 ? m->tok_emb_f.p : m->tok_emb_t.p; p.N = c.vocab; p.K = c.d_model; p.B = s->B; p.ldo = m->Vpad;
+        p.amax_val = s->amax_val.as<float>(); p.amax_idx = s->amax_idx.as<int>(); p.amax_stride = s->npart;
+        for (int i = 0; i < 3; ++i) { DISPATCH_DT(T, TT, launch_dec_logits<TT>(p, st)); launch_cross_attn(m, s, i, whole_batch(m, s)); }
+        p.dbg = dbg.as<long long>();
+        HIPCHK(hipEventRecord(e0, st));
+        DISPATCH_DT(T, TT, launch_dec_logits<TT>(p, st));
+        HIPCHK(hipEventRecord(e1, st));
+        HIPCHK(hipEventSynchronize(e1));
+        std::vector<long long> h((size_t)nwg * 64);
+        HIPCHK(hipMemcpy(h.data(), dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
+        long long t0 = -1;
+        for (int g = 0; g < nwg * 8; ++g) if (h[(size_t)g * 8] > 0 && (t0 < 0 || h[(size_t)g * 8] < t0)) t0 = h[(size_t)g * 8];
+        double mx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, av[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int n = 0;
+        for (int g = 0; g < nwg * 8; ++g) {
+            if (h[(size_t)g * 8] <= 0) continue;
+            ++n;
+            for (int k = 0; k < 7; ++k) {
+                const double us = (double)(h[(size_t)g * 8 + k] - t0) / 100.0;
+                av[k] += us;
+                mx[k] = std::max(mx[k], us);
+            }
+        }
+        fprintf(stderr, "[wm] logits phases (us after the first wave's entry; mean / max over %d waves): entry %.2f/%.2f  loads issued + staged %.2f/%.2f  after barrier %.2f/%.2f  MFMA done %.2f/%.2f  end %.2f/%.2f\n",
+                n, av[0] / n, mx[0], av[1] / n, mx[1], av[2] / n, mx[2], av[3] / n, mx[3], av[4] / n, mx[4]);
+        fprintf(stderr, "[wm]   gamma/beta + activations arrived (own wave) %.2f/%.2f  all waves of the workgroup %.2f/%.2f\n", av[5] / n, mx[5], av[6] / n, mx[6]);
+        dbg.release();
+#endif
     } else if (which == WM_KERNEL_ENCODER) {
         if (!s->last_mel) return fail(WM_E_STATE, "no mel was encoded into this state");
         WMCHK(run_encoder(m, s, s->last_mel, s->B, st));

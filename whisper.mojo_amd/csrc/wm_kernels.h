@@ -141,6 +141,7 @@ struct DecLinearParams {
     float* ts_s;
     long long* ts;  // developer timeline (dec_logits only)
     int ts_id;
+    long long* dbg;  // developer build: per-(workgroup, wave) phase stamps of dec_logits (100 MHz clock), null = off
 };
 template <typename TW> void launch_dec_linear(const DecLinearParams& p, hipStream_t st);
 bool dec_linear_supports_k(int K);  // K/32 k-steps must split into NW <= 16 waves x KPW <= 4 steps (checked at model load)
