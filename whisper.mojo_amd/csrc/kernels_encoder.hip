@@ -7,6 +7,7 @@
 #include "wm_kernels.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 namespace wm {
@@ -739,8 +740,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void flash_attn_enc_v2_kernel(const T
         for (int it = 0; it < NIT; ++it) {
             int krow = key0 + skey[it];
             krow = krow < n_ctx ? krow : n_ctx - 1;
-            kreg[it] = *reinterpret_cast<const t8*>(kbase + (size_t)krow * ld + sdch * 8);
-            vreg[it] = *reinterpret_cast<const t8*>(vbase + (size_t)krow * ld + sdch * 8);
+            const unsigned off = __umul24((unsigned)krow, (unsigned)ld) + sdch * 8;  // < 2^31 elements inside one utterance; full-rate multiply
+            kreg[it] = *reinterpret_cast<const t8*>(kbase + off);
+            vreg[it] = *reinterpret_cast<const t8*>(vbase + off);
         }
     };
     auto park = [&](int buf) {
@@ -754,9 +756,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void flash_attn_enc_v2_kernel(const T
     fetch(0);
     park(0);
     __syncthreads();
-    for (int t = 0; t < n_tiles; ++t) {
+    // One 64-key tile.  MASKED (keys past n_ctx set to -1e30) only for the LAST tile, as its own copy of the body: written as a
+    // run-time predicate the compiler keeps 16 v_cmp + 32 v_cndmask in every tile (48 of 155 VALU issues per tile, and this
+    // kernel is VALU-bound).  Scaling, exp2 argument, row sum and accumulator rescale are written on 4-vectors so that they
+    // become packed fp32 instructions (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two lanes of work per issue).
+    auto tile = [&](int t, auto MASKED, auto MORE) {
         const int buf = t & 1;
-        if (t + 1 < n_tiles) fetch((t + 1) * 64);
+        if constexpr (decltype(MORE)::value) fetch((t + 1) * 64);
         const T* Kt = Ks[buf];
         const T* Vt = Vs[buf];
         // Sᵀ = K·Qᵀ
@@ -772,7 +778,6 @@ __global__ __launch_bounds__(NW * 64, WPS) void flash_attn_enc_v2_kernel(const T
                 sc[qb][kb] = mma32(kf1, qf[qb][1], z);
             }
         }
-        const bool last = t == n_tiles - 1;
         Frag<T> pf[QB][2];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
@@ -783,27 +788,31 @@ __global__ __launch_bounds__(NW * 64, WPS) void flash_attn_enc_v2_kernel(const T
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = sc[qb][kb][r];
-                    if (last && t * 64 + kb * 16 + g * 4 + r >= n_ctx) v = -1e30f;
-                    sc[qb][kb][r] = v;
-                    tmax = fmaxf(tmax, v);
+                    if constexpr (decltype(MASKED)::value) {
+                        if (t * 64 + kb * 16 + g * 4 + r >= n_ctx) sc[qb][kb][r] = -1e30f;
+                    }
+                    tmax = fmaxf(tmax, sc[qb][kb][r]);
                 }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float m_new = fmaxf(m_run[qb], tmax * scale_log2e);
             const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
             m_run[qb] = m_new;
-            float psum = 0.f;
+            const f32x4 sl4 = f32x4{scale_log2e, scale_log2e, scale_log2e, scale_log2e}, nm4 = f32x4{-m_new, -m_new, -m_new, -m_new};
+            f32x4 ps4 = f32x4{0.f, 0.f, 0.f, 0.f};
             float pv[2][8];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+            for (int kb = 0; kb < 4; ++kb) {
+                const f32x4 a = __builtin_elementwise_fma(sc[qb][kb], sl4, nm4);
+                f32x4 pe;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qb][kb][r], scale_log2e, -m_new));
-                    psum += pe;
-                    pv[kb >> 1][(kb & 1) * 4 + r] = pe;
+                    pe[r] = __builtin_amdgcn_exp2f(a[r]);
+                    pv[kb >> 1][(kb & 1) * 4 + r] = pe[r];
                 }
-            l_run[qb] = l_run[qb] * alpha + psum;
+                ps4 += pe;
+            }
+            l_run[qb] = l_run[qb] * alpha + ((ps4[0] + ps4[1]) + (ps4[2] + ps4[3]));
 #pragma unroll
             for (int db = 0; db < 4; ++db) o[qb][db] *= alpha;
             pf[qb][0] = make_frag<T>(pv[0]);
@@ -822,9 +831,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void flash_attn_enc_v2_kernel(const T
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) o[qb][db] = mma32(vf, pf[qb][c], o[qb][db]);
             }
-        if (t + 1 < n_tiles) park(buf ^ 1);
-        __syncthreads();
-    }
+        if constexpr (decltype(MORE)::value) {
+            park(buf ^ 1);
+            __syncthreads();
+        }
+    };
+    for (int t = 0; t + 1 < n_tiles; ++t) tile(t, std::false_type{}, std::true_type{});
+    tile(n_tiles - 1, std::true_type{}, std::false_type{});
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         float l = l_run[qb];
