@@ -681,7 +681,7 @@ __device__ __forceinline__ f16x4 lds_tr16(const f16* p) {
     return __builtin_bit_cast(f16x4, v);
 }
 
-template <typename T, int NW, int QB, int WPS = 1>
+template <typename T, int NW, int QB, int WPS = 1, int OPT = 0>
 __global__ __launch_bounds__(NW * 64, WPS) void flash_attn_enc_v2_kernel(const T* __restrict__ qkv, T* __restrict__ out, int n_ctx,
                                                                     int d_model, float scale_log2e, int xcd_remap) {
     // 160-byte rows (40 dwords): with the hardware's lane groups (ds_read_b128: {0-3,12-15,20-27}, ...; ds_read_b64_tr:
@@ -735,14 +735,23 @@ __global__ __launch_bounds__(NW * 64, WPS) void flash_attn_enc_v2_kernel(const T
     const int skey[2] = {(int)threadIdx.x >> 3, ((int)threadIdx.x + 256) >> 3};
     const int sdch = threadIdx.x & 7;
     t8 kreg[NIT], vreg[NIT];
-    auto fetch = [&](int key0) {
+    // Global addresses as (uniform 64-bit base) + (32-bit byte offset per lane): the offset walks down the utterance by one
+    // tile per fetch and is clamped to the last valid key row — one v_add + one v_min per fetch instead of a 64-bit address
+    // rebuilt from the row index every tile.
+    const char* kb8 = reinterpret_cast<const char*>(kbase);
+    const char* vb8 = reinterpret_cast<const char*>(vbase);
+    unsigned boff[NIT], bmax;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) boff[it] = (unsigned)((size_t)skey[it] * ld + sdch * 8) * (unsigned)sizeof(T);
+    bmax = (unsigned)((size_t)(n_ctx - 1) * ld + sdch * 8) * (unsigned)sizeof(T);
+    const unsigned bstep = (unsigned)(64 * ld * sizeof(T));
+    auto fetch = [&]() {  // the next tile in sequence
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            int krow = key0 + skey[it];
-            krow = krow < n_ctx ? krow : n_ctx - 1;
-            const unsigned off = __umul24((unsigned)krow, (unsigned)ld) + sdch * 8;  // < 2^31 elements inside one utterance; full-rate multiply
-            kreg[it] = *reinterpret_cast<const t8*>(kbase + off);
-            vreg[it] = *reinterpret_cast<const t8*>(vbase + off);
+            const unsigned o = boff[it] < bmax ? boff[it] : bmax;
+            kreg[it] = *reinterpret_cast<const t8*>(kb8 + o);
+            vreg[it] = *reinterpret_cast<const t8*>(vb8 + o);
+            boff[it] += bstep;
         }
     };
     auto park = [&](int buf) {
@@ -753,7 +762,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void flash_attn_enc_v2_kernel(const T
         }
     };
     const int n_tiles = (n_ctx + 63) / 64;
-    fetch(0);
+    fetch();
     park(0);
     __syncthreads();
     // One 64-key tile.  MASKED (keys past n_ctx set to -1e30) only for the LAST tile, as its own copy of the body: written as a
@@ -762,7 +771,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void flash_attn_enc_v2_kernel(const T
     // become packed fp32 instructions (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two lanes of work per issue).
     auto tile = [&](int t, auto MASKED, auto MORE) {
         const int buf = t & 1;
-        if constexpr (decltype(MORE)::value) fetch((t + 1) * 64);
+        if constexpr (decltype(MORE)::value) fetch();
         const T* Kt = Ks[buf];
         const T* Vt = Vs[buf];
         // Sᵀ = K·Qᵀ
@@ -781,40 +790,56 @@ __global__ __launch_bounds__(NW * 64, WPS) void flash_attn_enc_v2_kernel(const T
         Frag<T> pf[QB][2];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            // running max kept in the exp2 domain (score * scale * log2 e); the per-score scaling rides the exp2 argument as
-            // one fma.  (Rescaling the accumulator only when a row's max moved was measured neutral and is not done.)
-            float tmax = -1e30f;
+            if constexpr (decltype(MASKED)::value) {
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+                for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if constexpr (decltype(MASKED)::value) {
+                    for (int r = 0; r < 4; ++r)
                         if (t * 64 + kb * 16 + g * 4 + r >= n_ctx) sc[qb][kb][r] = -1e30f;
-                    }
-                    tmax = fmaxf(tmax, sc[qb][kb][r]);
-                }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run[qb], tmax * scale_log2e);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
-            m_run[qb] = m_new;
-            const f32x4 sl4 = f32x4{scale_log2e, scale_log2e, scale_log2e, scale_log2e}, nm4 = f32x4{-m_new, -m_new, -m_new, -m_new};
-            f32x4 ps4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            float pv[2][8];
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                const f32x4 a = __builtin_elementwise_fma(sc[qb][kb], sl4, nm4);
-                f32x4 pe;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pe[r] = __builtin_amdgcn_exp2f(a[r]);
-                    pv[kb >> 1][(kb & 1) * 4 + r] = pe[r];
-                }
-                ps4 += pe;
             }
-            l_run[qb] = l_run[qb] * alpha + ((ps4[0] + ps4[1]) + (ps4[2] + ps4[3]));
+            // Softmax in the exp2 domain against a REFERENCE maximum m_run that is only refreshed when it has to be.  Any reference
+            // gives the same softmax as long as nothing overflows (p, the row sum and the accumulator scale together; fp32 and
+            // bf16 share their exponent range), so the fast path takes p = exp2(s * scale*log2e - m_run) with the reference as it
+            // stands: no row maximum (8 v_max3 + 6 v_max + two cross-lane round trips), no alpha, no accumulator rescale.
+            // A wave takes the exact path (refresh the reference to the running maximum, as before) when one of its rows'
+            // partial sums leaves [0, 1024]: always on the first tile (m_run = -1e30 gives inf), and whenever a row's scores
+            // have outgrown its reference by ~2^6 or more.
+            const f32x4 sl4 = f32x4{scale_log2e, scale_log2e, scale_log2e, scale_log2e};
+            float pv[2][8];
+            auto probs = [&](float m) {  // p of this lane's 16 scores against reference m; returns their sum
+                const f32x4 nm4 = f32x4{-m, -m, -m, -m};
+                f32x4 ps4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int db = 0; db < 4; ++db) o[qb][db] *= alpha;
+                for (int kb = 0; kb < 4; ++kb) {
+                    const f32x4 a = __builtin_elementwise_fma(sc[qb][kb], sl4, nm4);
+                    f32x4 pe;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pe[r] = __builtin_amdgcn_exp2f(a[r]);
+                        pv[kb >> 1][(kb & 1) * 4 + r] = pe[r];
+                    }
+                    ps4 += pe;
+                }
+                return (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+            };
+            float psum = (OPT & 1) ? INFINITY : probs(m_run[qb]);
+            if (__any(!(psum <= 1024.f))) {
+                float tmax = -1e30f;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, sc[qb][kb][r]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_run[qb], tmax * scale_log2e);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+                m_run[qb] = m_new;
+                psum = probs(m_new);
+                l_run[qb] *= alpha;
+#pragma unroll
+                for (int db = 0; db < 4; ++db) o[qb][db] *= alpha;
+            }
+            l_run[qb] += psum;
             pf[qb][0] = make_frag<T>(pv[0]);
             pf[qb][1] = make_frag<T>(pv[1]);
         }
@@ -883,6 +908,9 @@ void launch_flash_attn_enc(const void* qkv, void* out, int B, int H, int n_ctx, 
             return;
         } else if (var == 4) {
             hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 4, 2>), dim3((n_ctx + 127) / 128, H, B), dim3(256), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, rm);
+            return;
+        } else if (var == 5) {  // exact running maximum on every tile
+            hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 8, 1, 6, 1>), dim3((n_ctx + 127) / 128, H, B), dim3(512), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, rm);
             return;
         } else if (wps1 || no_xcd) {
             hipLaunchKernelGGL((flash_attn_enc_v2_kernel<T, 8, 1, 1>), dim3((n_ctx + 127) / 128, H, B), dim3(512), 0, st, (const T*)qkv, (T*)out, n_ctx, H * 64, sl, rm);
