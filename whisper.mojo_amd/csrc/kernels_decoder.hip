@@ -66,6 +66,12 @@ __device__ __forceinline__ void store_as(void* base, size_t idx, float v, int dt
 template <typename TW, int KPW, bool LN, int NT, bool XT = false>
 __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
     static_assert(!(LN && XT), "the LayerNorm prologue reads the fp32 residual stream");
+#ifdef WM_DEV
+#define WM_DL_STAMP(k) do { if (p.dbg && (threadIdx.x & 63) == 0) p.dbg[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (threadIdx.x >> 6)) * 8 + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define WM_DL_STAMP(k) do { } while (0)
+#endif
+    WM_DL_STAMP(0);
     // dynamic LDS, sized by the launcher for the NW waves actually used: [NW][NT][64] f32x4 K-partials, then [NW][16][2]
     // LayerNorm statistics (24.6 + 1.5 KB for the 12-wave QKV / fc1 launches: fits beside two 64-KB GEMM workgroups)
     extern __shared__ __attribute__((aligned(16))) unsigned char dl_smem[];
@@ -98,16 +104,27 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
             for (int r = 0; r < 4; ++r) bias4[r] = p.bias[min(en + r, p.N - 1)];
         }
         if (p.residual) res4 = *reinterpret_cast<const f32x4*>(p.residual + (size_t)eb * p.ldr + en);
+        // (a VECTOR load: the scalar form would put another scalar round trip — kernarg -> ctl -> len — in front of the weight loads)
+#ifdef WM_SCALAR_LEN  // developer A/B
         if (p.kcache) cache_row = p.ctl->len;
+#else
+        if (p.kcache) cache_row = __builtin_nontemporal_load(&p.ctl->len);
+#endif
     }
     Frag<TW> wf[NT][KPW];
     Frag<TW> xft[XT ? KPW : 1];
     f32x4 xa[XT ? 1 : KPW][2], gb[LN ? KPW : 1][4];
+    // every weight load first: they come from HBM / MALL (~1 us), the activation and LayerNorm loads behind them are L2 hits,
+    // and a wave issues loads only as fast as the CU's address path takes them (24 x 1 KB per wave here)
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
         const int k = (w + nw * i) * 32;
 #pragma unroll
         for (int t = 0; t < NT; ++t) wf[t][i] = load_frag<TW>(wp[t] + k);
+    }
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int k = (w + nw * i) * 32;
         if constexpr (XT) {
             xft[i] = load_frag<TW>(xpt + k);
         } else {
@@ -121,6 +138,7 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
             gb[i][3] = *reinterpret_cast<const f32x4*>(p.ln_b + k + g * 8 + 4);
         }
     }
+    WM_DL_STAMP(1);
     float mean = 0.f, rstd = 1.f;
     if constexpr (LN) {
         float sm = 0.f, sq = 0.f;
@@ -153,6 +171,7 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
         const float var = (sq / (float)p.K) - (mean * mean);
         rstd = 1.0f / sqrtf(var + 1e-5f);
     }
+    WM_DL_STAMP(2);
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -182,7 +201,9 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) s_red[w][t][lane] = acc[t];
+    WM_DL_STAMP(3);
     __syncthreads();
+    WM_DL_STAMP(4);
     if (epi) {
         f32x4 v = s_red[0][w][lane];
         for (int k = 1; k < nw; ++k) v += s_red[k][w][lane];
@@ -216,7 +237,9 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
             *reinterpret_cast<f32x4*>(p.out + (size_t)eb * p.ldo + en) = v;
         }
     }
+    WM_DL_STAMP(5);
 }
+#undef WM_DL_STAMP
 template <typename TW, int KPW> static void launch_dec_linear_t(const DecLinearParams& p, int nw, hipStream_t st) {
     // two column tiles per workgroup for the wide projections (QKV, fc1): half the workgroups, one activation
     // fragment (and one LayerNorm) feeding two MFMAs
@@ -636,7 +659,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecParams p) {
     const int LPR = p.H * LPH;
     const int RPS = p.rps;  // key rows swept per step = active threads / LPR
     const int bk = (NQ == 1 && p.q_B > 0) ? b % p.q_B : b;  // utterance whose K/V this workgroup reads
-    const int len = p.n_keys >= 0 ? p.n_keys : p.ctl->len + 1 + ((NQ == 1 && p.q_B > 0) ? b / p.q_B : 0);
+    const int len = p.n_keys >= 0 ? p.n_keys : p.ctl->len + 1 + ((NQ == 1 && p.q_B > 0) ? b / p.q_B : 0);  // (scalar chain kernarg -> ctl -> len: the loop bounds need it before any K/V row is requested)
     const int qstride = NQ > 1 ? p.q_B : 0;  // query / output row of position t: b + t * qstride
     const int chunk = (len + p.nsplit - 1) / p.nsplit;
     const int j0 = split * chunk;

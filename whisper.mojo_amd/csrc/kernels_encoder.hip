@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmParams p) {
 // s_barrier: the ring never drains).  A workgroup walks a contiguous range of (panel, column tile) units, column tile
 // fastest, so a panel's A fragments are fetched by one or two workgroups.  Bias is folded into the accumulator
 // initialisation from an LDS copy (no VMEM loads inside the stream).  No residual / positional addends (launcher).
-template <typename T, typename TO, int KS /* K / 32 */>
+template <typename T, typename TO, int KS /* K / 32 */, bool LNA = false /* A = fp32 rows, LayerNorm applied while loading */>
 __global__ __launch_bounds__(256, 2) void gemm_nt_rowpanel_kernel(GemmParams p, int n_units) {
     constexpr int SPU = KS / 2;       // 64-k stages per unit
     constexpr int NSLOT = 4;          // ring slots of 128 rows x 64 k
@@ -278,6 +278,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_rowpanel_kernel(GemmParams p, 
     const int n_stage = (u1 - u0) * SPU;
     const T* Wg = (const T*)p.W;
     for (int i = threadIdx.x; i < p.N; i += 256) s_bias[i] = p.bias ? p.bias[i] : 0.f;
+    float* s_gb = s_bias + p.N;  // LNA: gamma [K], beta [K]
+    if constexpr (LNA) {
+        for (int i = threadIdx.x; i < KS * 32; i += 256) {
+            s_gb[i] = p.ln_g[i];
+            s_gb[KS * 32 + i] = p.ln_b[i];
+        }
+    }
     __syncthreads();  // before any DMA is in flight: a __syncthreads() later would drain the ring (vmcnt(0))
 
     auto issue = [&](int s) {  // stage s of this workgroup's stream -> ring slot s % 4
@@ -303,9 +310,54 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_rowpanel_kernel(GemmParams p, 
             for (int i = 0; i < 2; ++i) {
                 int row = pn * 128 + w * 32 + i * 16 + r16;
                 row = row < p.M ? row : p.M - 1;
-                const T* ar = (const T*)p.A + (size_t)row * p.lda + g * 8;
+                if constexpr (LNA) {
+                    // The fp32 residual row instead of its normalised 16-bit copy: a lane holds 8 of every 32 columns (the four
+                    // lanes r16, r16+16, +32, +48 share the row), so the statistics are a sum over the lane's KS*8 values and two
+                    // butterfly steps; one-pass variance and operation order as layernorm_rows_kernel (whisper_tensor.mojo:249-285).
+                    const float* xr = (const float*)p.A + (size_t)row * p.lda + g * 8;
+                    f32x4 xv[KS][2];
 #pragma unroll
-                for (int k = 0; k < KS; ++k) a[i][k] = load_frag<T>(ar + k * 32);
+                    for (int k = 0; k < KS; ++k) {
+                        xv[k][0] = *reinterpret_cast<const f32x4*>(xr + k * 32);
+                        xv[k][1] = *reinterpret_cast<const f32x4*>(xr + k * 32 + 4);
+                    }
+                    float sm = 0.f, sq = 0.f;
+#pragma unroll
+                    for (int k = 0; k < KS; ++k)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                sm += xv[k][h][e];
+                                sq += xv[k][h][e] * xv[k][h][e];
+                            }
+                    sm += __shfl_xor(sm, 16, 64);
+                    sq += __shfl_xor(sq, 16, 64);
+                    sm += __shfl_xor(sm, 32, 64);
+                    sq += __shfl_xor(sq, 32, 64);
+                    const float mean = sm / (float)(KS * 32);
+                    const float var = (sq / (float)(KS * 32)) - (mean * mean);
+                    const float inv_std = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) {
+                        float y[8];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const f32x4 gm = *reinterpret_cast<const f32x4*>(&s_gb[k * 32 + g * 8 + h * 4]);
+                            const f32x4 bt = *reinterpret_cast<const f32x4*>(&s_gb[KS * 32 + k * 32 + g * 8 + h * 4]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[h * 4 + e] = (xv[k][h][e] - mean) * inv_std * gm[e] + bt[e];
+                        }
+                        a[i][k] = make_frag<T>(y);
+                    }
+                    // one half-panel at a time: with both halves' 2 x 96 fp32 values in flight together the kernel spills, and a
+                    // reload inside the steady-state loop costs an s_waitcnt vmcnt(0) that drains the DMA ring
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    const T* ar = (const T*)p.A + (size_t)row * p.lda + g * 8;
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) a[i][k] = load_frag<T>(ar + k * 32);
+                }
             }
         }
 #pragma unroll
@@ -437,20 +489,35 @@ template <typename T, typename TO, int KS> static void launch_rowpanel(const Gem
     const int n_units = ((p.M + 127) / 128) * (p.N / 128);
     static const int grid_max = wm_env("WM_RP_GRID") ? atoi(wm_env("WM_RP_GRID")) : 512;  // two 64-KB-ring workgroups per CU
     const int grid = std::min(n_units, grid_max);
-    const size_t lds = (size_t)4 * 128 * 64 * sizeof(T) + (size_t)p.N * 4;
+    const size_t lds = (size_t)4 * 128 * 64 * sizeof(T) + (size_t)p.N * 4 + (p.ln_g ? (size_t)2 * KS * 32 * 4 : 0);
+    if (p.ln_g) {
+        (void)ensure_dyn_lds(&gemm_nt_rowpanel_kernel<T, TO, KS, true>, 80 * 1024);
+        hipLaunchKernelGGL((gemm_nt_rowpanel_kernel<T, TO, KS, true>), dim3(grid), dim3(256), lds, st, p, n_units);
+        return;
+    }
     (void)ensure_dyn_lds(&gemm_nt_rowpanel_kernel<T, TO, KS>, 80 * 1024);  // per device; a failure surfaces through hipGetLastError
     hipLaunchKernelGGL((gemm_nt_rowpanel_kernel<T, TO, KS>), dim3(grid), dim3(256), lds, st, p, n_units);
 }
+static bool rowpanel_ok(int operand_bytes, const GemmParams& p, int batch) {
+    // A-stationary row-panel kernel: plain [M,K]x[N,K] (no conv batching), K = 384 (K = 512 needs 128 A registers: spills), no addends, N <= 3072
+    static const bool off = wm_env("WM_GEMM_NO_ROWPANEL") != nullptr || wm_env("WM_GEMM_DIRECT") != nullptr;
+    return operand_bytes == 2 && !off && batch == 1 && !p.residual && !p.pos && p.K == 384 && p.N <= 3072 && (p.N & 127) == 0 &&
+           (p.group_n == 0 || p.group_n % 128 == 0);
+}
+bool gemm_nt_fuses_layernorm(int operand_bytes, const GemmParams& p, int batch) {
+    static const bool off = wm_env("WM_GEMM_NO_LN_FUSE") != nullptr;
+    return !off && rowpanel_ok(operand_bytes, p, batch);
+}
 
 template <typename T, typename TO> void launch_gemm_nt(const GemmParams& p, int batch, hipStream_t st) {
+    if (p.ln_g && !rowpanel_ok((int)sizeof(T), p, batch)) {  // caller bug (see gemm_nt_fuses_layernorm): refuse rather than multiply un-normalised rows
+        fprintf(stderr, "[whispermi] gemm_nt: fused LayerNorm asked of a shape only the plain kernels take - launch skipped\n");
+        return;
+    }
     dim3 grid(p.N / 128, (p.M + 127) / 128, batch);
     static const bool no_lds = wm_env("WM_GEMM_DIRECT") != nullptr;
     if constexpr (sizeof(T) == 2) {
-        // A-stationary row-panel kernel: plain [M,K]x[N,K] (no conv batching), K = 384 (K = 512 needs 128 A registers: spills), no addends, N <= 3072
-        static const bool no_rp = wm_env("WM_GEMM_NO_ROWPANEL") != nullptr;
-        if (!no_rp && !no_lds && batch == 1 && !p.residual && !p.pos && p.N <= 3072 && (p.group_n == 0 || p.group_n % 128 == 0)) {
-            if (p.K == 384) return launch_rowpanel<T, TO, 12>(p, st);
-        }
+        if (rowpanel_ok((int)sizeof(T), p, batch)) return launch_rowpanel<T, TO, 12>(p, st);
         if (!no_lds && (p.K & 63) == 0) {
             static const bool no_remap = wm_env("WM_GEMM_NOXCD") != nullptr;
             GemmParams q = p;

@@ -255,6 +255,19 @@ struct wm_state {
         }                                    \
     } while (0)
 
+static void gemm_dispatch(int dt_in, int dt_out, const GemmParams& p, int batch, hipStream_t st);
+// C = LN(x) W^T (+ epilogue of p): p.A names the scratch for the normalised rows.  The A-stationary GEMM normalises the fp32 rows
+// while it loads them (no LayerNorm launch, no 16-bit copy through HBM); every other shape runs layernorm_rows first.
+static void ln_then_gemm(int dt_in, int dt_out, GemmParams p, const float* x, const float* g, const float* b, hipStream_t st) {
+    if (gemm_nt_fuses_layernorm(dt_in == WM_F32 ? 4 : 2, p, 1)) {
+        p.A = x;
+        p.ln_g = g;
+        p.ln_b = b;
+    } else {
+        DISPATCH_DT(dt_in, TT, launch_layernorm_rows<TT>(x, g, b, const_cast<void*>(p.A), nullptr, p.M, p.K, 1e-5f, st));
+    }
+    gemm_dispatch(dt_in, dt_out, p, 1, st);
+}
 static void gemm_dispatch(int dt_in, int dt_out, const GemmParams& p, int batch, hipStream_t st) {
     if (dt_in == WM_F32) {
         launch_gemm_nt<float, float>(p, batch, st);
@@ -894,7 +907,6 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
         }
         for (int l = 0; l < c.n_layers; ++l) {  // layers.mojo:435-519 with is_decoder=False
             EncLayer& w = m->enc[l];
-            DISPATCH_DT(T, TT, launch_layernorm_rows<TT>(s->x.as<float>(), w.ln1_g.as<float>(), w.ln1_b.as<float>(), s->xn.p, nullptr, M, c.d_model, 1e-5f, st));
             GemmParams p{};
             p.A = s->xn.p;
             p.W = w.qkv_w.p;
@@ -906,7 +918,7 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
             p.ldw = d;
             p.ldc = 3 * d;
             p.bias = w.qkv_b.as<float>();
-            gemm_dispatch(T, T, p, 1, st);
+            ln_then_gemm(T, T, p, s->x.as<float>(), w.ln1_g.as<float>(), w.ln1_b.as<float>(), st);
             DISPATCH_DT(T, TT, launch_flash_attn_enc<TT>(s->qkv.p, s->ao.p, bc, c.n_heads, c.n_audio_ctx, scale, st));
             GemmParams o{};
             o.A = s->ao.p;
@@ -922,7 +934,6 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
             o.residual = s->x.as<float>();
             o.ldr = d;
             gemm_dispatch(T, WM_F32, o, 1, st);
-            DISPATCH_DT(T, TT, launch_layernorm_rows<TT>(s->x.as<float>(), w.ln2_g.as<float>(), w.ln2_b.as<float>(), s->xn.p, nullptr, M, c.d_model, 1e-5f, st));
             GemmParams f1{};
             f1.A = s->xn.p;
             f1.W = w.fc1_w.p;
@@ -936,7 +947,7 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
             f1.bias = w.fc1_b.as<float>();
             f1.act = 1;
             f1.gelu_mode = m->cfg.gelu_mode;
-            gemm_dispatch(T, T, f1, 1, st);
+            ln_then_gemm(T, T, f1, s->x.as<float>(), w.ln2_g.as<float>(), w.ln2_b.as<float>(), st);
             GemmParams f2{};
             f2.A = s->hid.p;
             f2.W = w.fc2_w.p;
@@ -1745,6 +1756,48 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
         (void)hipGraphExecDestroy(ge);
         s->shares_chip = false;
 #ifdef WM_DEV
+    } else if (which == 41 || which == 42) {  // developer: phase stamps of one LN1 + QKV (41) / O-proj (42) launch
+        const wm_dims& c = m->cfg.dims;
+        const int T = dec_dtype(m->cfg);
+        DecLayer& w0 = m->dec[0];
+        DevBuf dbg;
+        WMCHK(dbg.alloc((size_t)4096 * 16 * 8 * 8, true));
+        DecLinearParams p{};
+        p.B = s->B;
+        if (which == 41) {
+            p.x = s->dx.as<float>(); p.ldx = c.d_model; p.ln_g = w0.ln1_g.as<float>(); p.ln_b = w0.ln1_b.as<float>();
+            p.W = w0.sqkv_w.p; p.N = 3 * c.d_model; p.K = c.d_model; p.bias = w0.sqkv_b.as<float>(); p.out = s->dq.as<float>();
+            p.ldo = c.d_model; p.kcache = s->self_kv.p; p.vcache = off_bytes(s->self_kv, (size_t)s->B * c.n_text_ctx * c.d_model * dt_size(m->cfg.kv_dtype));
+            p.kv_batch_stride = (long)((size_t)c.n_text_ctx * c.d_model); p.d_model = c.d_model; p.kv_dtype = m->cfg.kv_dtype; p.ctl = s->ctl.as<StepCtl>();
+        } else {
+            p.x = s->dattn.as<float>(); p.ldx = c.d_model; p.x_is_t = 1; p.W = w0.so_w.p; p.N = c.d_model; p.K = c.d_model; p.bias = w0.so_b.as<float>();
+            p.residual = s->dx.as<float>(); p.ldr = c.d_model; p.out = s->dx.as<float>(); p.ldo = c.d_model;
+        }
+        launch_set_step(s->ctl.as<StepCtl>(), 10, 1, nullptr, 0, nullptr, 0, s->B, st);
+        for (int i = 0; i < 3; ++i) { dec_linear_dispatch(T, p, st); launch_cross_attn(m, s, i, whole_batch(m, s)); }
+        p.dbg = dbg.as<long long>();
+        HIPCHK(hipEventRecord(e0, st));
+        dec_linear_dispatch(T, p, st);
+        HIPCHK(hipEventRecord(e1, st));
+        HIPCHK(hipEventSynchronize(e1));
+        std::vector<long long> h((size_t)4096 * 16 * 8);
+        HIPCHK(hipMemcpy(h.data(), dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
+        long long t0 = -1;
+        for (size_t g = 0; g < h.size() / 8; ++g) if (h[g * 8] > 0 && (t0 < 0 || h[g * 8] < t0)) t0 = h[g * 8];
+        double mx[6] = {0}, av[6] = {0};
+        int n = 0;
+        for (size_t g = 0; g < h.size() / 8; ++g) {
+            if (h[g * 8] <= 0) continue;
+            ++n;
+            for (int k = 0; k < 6; ++k) {
+                const double us = (double)(h[g * 8 + k] - t0) / 100.0;
+                av[k] += us;
+                mx[k] = std::max(mx[k], us);
+            }
+        }
+        fprintf(stderr, "[wm] dec_linear %s phases (us after the first wave's entry; mean / max over %d waves): entry %.2f/%.2f  loads issued %.2f/%.2f  operands ready %.2f/%.2f  MFMA + partial stored %.2f/%.2f  after barrier %.2f/%.2f  end %.2f/%.2f\n",
+                which == 41 ? "LN1+QKV" : "O-proj", n, av[0] / n, mx[0], av[1] / n, mx[1], av[2] / n, mx[2], av[3] / n, mx[3], av[4] / n, mx[4], av[5] / n, mx[5]);
+        dbg.release();
     } else if (which == 40) {  // developer: phase stamps of one logits launch (after a few warm ones), printed to stderr
         const wm_dims& c = m->cfg.dims;
         const int T = dec_dtype(m->cfg);

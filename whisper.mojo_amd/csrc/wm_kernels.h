@@ -54,7 +54,13 @@ struct GemmParams {
     int group_n;  // >0: column n goes to C + (n/group_n)*group_stride + m*ldc + n%group_n  (cross-K/V scatter)
     long group_stride;
     int xcd_remap;  // set by the launcher (LDS-staged kernel only)
+    // LayerNorm fused into the A load (row-panel kernel only — ask gemm_nt_fuses_layernorm first): A is then the fp32 residual
+    // stream [M][lda] and the operand is LN(A) * ln_g + ln_b rounded to T, exactly what layernorm_rows + a plain GEMM compute
+    const float* ln_g;
+    const float* ln_b;
 };
+// true when launch_gemm_nt<T, *> takes the A-stationary row-panel kernel for these parameters (the only one that can fuse a LayerNorm)
+bool gemm_nt_fuses_layernorm(int operand_bytes, const GemmParams& p, int batch);
 template <typename T> void launch_mel_transpose_pad(const float* mel, void* out, int B, int C, int L, int Cp, hipStream_t st);
 template <typename T, typename TO> void launch_gemm_nt(const GemmParams& p, int batch, hipStream_t st);
 template <typename T>
