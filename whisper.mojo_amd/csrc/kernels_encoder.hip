@@ -509,9 +509,263 @@ bool gemm_nt_fuses_layernorm(int operand_bytes, const GemmParams& p, int batch) 
     return !off && rowpanel_ok(operand_bytes, p, batch);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Full-row GEMM for the residual-stream writers (O-proj, fc2, conv2: N = 384, fp32 out): one workgroup owns 128 COMPLETE output
+// rows, so (a) the A rows are staged once instead of once per 128-column tile, (b) a barrier covers 24 MFMAs per wave on a
+// 32-deep stage of 32 KB ([A 128 rows ; W 384 rows] x 32 k) instead of 32 per 64-deep stage of 32 KB for a third of the
+// columns, and (c) the epilogue holds whole rows: it can write the NEXT LayerNorm's 16-bit operand rows next to the fp32
+// residual stream (no LayerNorm launch, no second read of the 147 MB stream).
+// 512 threads: wave (wr, wc) = rows 32 wr .. +32, columns 192 wc .. +192 (96 accumulator registers).  Stages go
+// global -> LDS by global_load_lds into a 4-slot ring, three stages ahead, counted vmcnt + raw s_barrier (as the row-panel
+// kernel).  LDS rows are 64 B; the 16-byte chunk g of row r lives at position g ^ (-(r >> 2) & 3): with ds_read_b128's lane
+// groups ({0-3, 12-15, 20-27}, ...) the four (row group, g) pairs of a group then take the four chunk positions once each.
+template <typename T, bool LNO>
+__global__ __launch_bounds__(512) void gemm_nt_fullrow_kernel(GemmParams p) {
+    constexpr int NSLOT = 4, SLOT = 512 * 32;  // elements per ring slot
+    extern __shared__ __attribute__((aligned(16))) unsigned char fr_smem[];
+    T* ring = reinterpret_cast<T*>(fr_smem);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int wr = w >> 1, wc = w & 1;
+    const int bz = blockIdx.y, m0 = blockIdx.x * 128;
+    const T* A = (const T*)p.A + (size_t)bz * p.strideA;
+    const T* W = (const T*)p.W;
+    f32x4 acc[12][2];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // DMA sources: 32 one-KiB pieces per stage (16 rows x 64 B each); wave w stages pieces 4w .. 4w+3 — waves 0-1 the A rows
+    const T* src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 16 * (w * 4 + j) + (lane >> 2), pos = lane & 3;
+        const int c = pos ^ ((4 - ((row >> 2) & 3)) & 3);
+        if (w < 2) {
+            int ar = m0 + row;
+            ar = ar < p.M ? ar : p.M - 1;
+            src[j] = A + (size_t)ar * p.lda + c * 8;
+        } else {
+            src[j] = W + (size_t)(row - 128) * p.ldw + c * 8;
+        }
+    }
+    const int n_stage = p.K >> 5;
+    auto issue = [&](int s) {
+        T* slot = ring + (s & (NSLOT - 1)) * SLOT + w * 4 * 512;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + s * 32),
+                                             (__attribute__((address_space(3))) void*)(slot + j * 512), 16, 0, 0);
+    };
+#pragma unroll
+    for (int s = 0; s < NSLOT - 1; ++s)
+        if (s < n_stage) issue(s);
+    const int pofs = (g ^ ((4 - (r16 >> 2)) & 3)) << 3;  // every fragment row is r16 (mod 16)
+    // Software pipeline over stages with two fragment sets: step s multiplies the fragments of stage s (read from LDS during
+    // step s-1) while the 14 fragments of stage s+1 are being read — with one workgroup per CU and every wave on the same
+    // barrier nothing else covers the LDS latency.  The fragment reads and their waits are inline asm: hipcc's own wait
+    // insertion cannot express "all but the 14 youngest LDS reads" across the loop's back edge and puts lgkmcnt(0) in front of
+    // the first MFMA, i.e. waits for the reads just issued.  Protocol per step s:
+    //   top   s_waitcnt vmcnt(4|0): stage s+1 has landed (at most the one younger stage, 4 DMAs of this wave's, outstanding);
+    //         s_barrier: every wave is past the lgkmcnt wait of step s-1, i.e. holds stage s-1 AND s in registers, so slot
+    //         (s-1) % 4 is free: the DMAs of stage s+3 go there
+    //   then  14 ds_read_b128 of stage s+1 -> the other register set;  s_waitcnt lgkmcnt(14) (LDS returns in order: everything
+    //         but those 14 is complete, so stage s is in registers);  24 MFMAs on stage s.
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)fr_smem;
+    const unsigned offA = lds0 + (unsigned)(((wr * 32 + r16) * 32 + pofs) * sizeof(T));
+    const unsigned offW = lds0 + (unsigned)(((128 + wc * 192 + r16) * 32 + pofs) * sizeof(T));
+    auto read_frags = [&](int s, i32x4(&a)[2], i32x4(&bf)[12]) {
+        const unsigned so = (unsigned)(s & (NSLOT - 1)) * (unsigned)(SLOT * sizeof(T));
+        const unsigned pa = offA + so, pw = offW + so;
+        asm volatile(
+            "ds_read_b128 %0, %14\n\tds_read_b128 %1, %14 offset:1024\n\t"
+            "ds_read_b128 %2, %15\n\tds_read_b128 %3, %15 offset:1024\n\tds_read_b128 %4, %15 offset:2048\n\t"
+            "ds_read_b128 %5, %15 offset:3072\n\tds_read_b128 %6, %15 offset:4096\n\tds_read_b128 %7, %15 offset:5120\n\t"
+            "ds_read_b128 %8, %15 offset:6144\n\tds_read_b128 %9, %15 offset:7168\n\tds_read_b128 %10, %15 offset:8192\n\t"
+            "ds_read_b128 %11, %15 offset:9216\n\tds_read_b128 %12, %15 offset:10240\n\tds_read_b128 %13, %15 offset:11264"
+            : "=&v"(a[0]), "=&v"(a[1]), "=&v"(bf[0]), "=&v"(bf[1]), "=&v"(bf[2]), "=&v"(bf[3]), "=&v"(bf[4]), "=&v"(bf[5]),
+              "=&v"(bf[6]), "=&v"(bf[7]), "=&v"(bf[8]), "=&v"(bf[9]), "=&v"(bf[10]), "=&v"(bf[11])
+            : "v"(pa), "v"(pw)
+            : "memory");
+    };
+#define WM_FR_HOLD(A, B)                                                                                                              \
+    "+v"(A[0]), "+v"(A[1]), "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]), "+v"(B[4]), "+v"(B[5]), "+v"(B[6]), "+v"(B[7]), "+v"(B[8]), \
+        "+v"(B[9]), "+v"(B[10]), "+v"(B[11])
+    auto mfmas = [&](const i32x4(&a)[2], const i32x4(&bf)[12]) {
+        Frag<T> fa[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i].v = __builtin_bit_cast(decltype(fa[i].v), a[i]);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            Frag<T> fb;
+            fb.v = __builtin_bit_cast(decltype(fb.v), bf[j]);
+            acc[j][0] = mma32(fb, fa[0], acc[j][0]);
+            acc[j][1] = mma32(fb, fa[1], acc[j][1]);
+        }
+    };
+    auto step = [&](int st, i32x4(&ac)[2], i32x4(&bc)[12], i32x4(&an)[2], i32x4(&bn)[12], auto YOUNGER, auto REFILL) {
+        if constexpr (decltype(YOUNGER)::value)
+            asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (decltype(REFILL)::value) issue(st + NSLOT - 1);
+        read_frags(st + 1, an, bn);
+        asm volatile("s_waitcnt lgkmcnt(14)" : WM_FR_HOLD(ac, bc)::"memory");
+        mfmas(ac, bc);
+    };
+    i32x4 a0[2], b0[12], a1[2], b1[12];
+    if (n_stage >= 4)
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");  // n_stage == 2 (K = 64)
+    read_frags(0, a0, b0);
+    // n_stage is even (launcher: K % 64 == 0).  Straight-line steady state (one wait constant, unconditional refills), then the
+    // last four stages with their shorter queues.
+    int s = 0;
+    for (; s + 6 <= n_stage; s += 2) {
+        step(s, a0, b0, a1, b1, std::true_type{}, std::true_type{});
+        step(s + 1, a1, b1, a0, b0, std::true_type{}, std::true_type{});
+    }
+    if (n_stage >= 4) {  // s == n_stage - 4
+        step(s, a0, b0, a1, b1, std::true_type{}, std::true_type{});
+        step(s + 1, a1, b1, a0, b0, std::true_type{}, std::false_type{});
+        s += 2;
+    }
+    step(s, a0, b0, a1, b1, std::false_type{}, std::false_type{});  // s == n_stage - 2
+    asm volatile("s_waitcnt lgkmcnt(0)" : WM_FR_HOLD(a1, b1)::"memory");
+    mfmas(a1, b1);
+#undef WM_FR_HOLD
+    // epilogue: acc[j][i][r] = C[m0 + 32 wr + 16 i + r16][192 wc + 16 j + 4 g + r];  out = act(acc) + pos + residual
+    float* Cb = (float*)p.C + (size_t)bz * p.strideC;
+    float sm[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wr * 32 + i * 16 + r16;
+        const bool valid = m < p.M;
+        const int ml = valid ? m : p.M - 1;
+        f32x4 ex[12], bv[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            ex[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bv[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + wc * 192 + j * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (p.residual) {
+            const float* rr = p.residual + (size_t)bz * p.strideR + (size_t)ml * p.ldr + wc * 192 + g * 4;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) ex[j] = *reinterpret_cast<const f32x4*>(rr + j * 16);
+        }
+        if (p.pos) {
+            const float* pr = p.pos + (size_t)ml * p.N + wc * 192 + g * 4;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) ex[j] += *reinterpret_cast<const f32x4*>(pr + j * 16);
+        }
+        float* crow = Cb + (size_t)ml * p.ldc + wc * 192 + g * 4;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            f32x4 v = acc[j][i] + bv[j];
+            if (p.act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r], p.gelu_mode);
+            }
+            v += ex[j];
+            if (valid) *reinterpret_cast<f32x4*>(crow + j * 16) = v;
+            if constexpr (LNO) {
+                acc[j][i] = v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sm[i] += v[r];
+                    sq[i] += v[r] * v[r];
+                }
+            }
+        }
+    }
+    if constexpr (LNO) {
+        // LayerNorm of the finished rows (one-pass variance, whisper_tensor.mojo:249-285).  A row's 384 columns sit in 2 waves x 4
+        // lanes: butterfly over the lanes, the two column halves meet in LDS (the ring is free: the loop's last barrier plus this
+        // one mean every wave has read its last fragment).
+        constexpr int PITCH = 400;  // bytes per scratch row (384 + 16: 100 dwords, 36 mod 64 — 16 rows' 8-byte stores on distinct banks)
+        float* s_stat = reinterpret_cast<float*>(fr_smem + 8 * 32 * PITCH);  // [128 rows][2 halves][2]
+        unsigned char* scr = fr_smem + w * 32 * PITCH;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            sm[i] += __shfl_xor(sm[i], 16, 64);
+            sq[i] += __shfl_xor(sq[i], 16, 64);
+            sm[i] += __shfl_xor(sm[i], 32, 64);
+            sq[i] += __shfl_xor(sq[i], 32, 64);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (g == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float* st = s_stat + ((wr * 32 + i * 16 + r16) * 2 + wc) * 2;
+                st[0] = sm[i];
+                st[1] = sq[i];
+            }
+        }
+        __syncthreads();
+        typedef __attribute__((ext_vector_type(4))) T t4;
+        typedef __attribute__((ext_vector_type(8))) T t8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* st = s_stat + (wr * 32 + i * 16 + r16) * 4;
+            const float s1 = st[0] + st[2], s2 = st[1] + st[3];
+            const float mean = s1 / 384.0f;
+            const float var = (s2 / 384.0f) - (mean * mean);
+            const float inv_std = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(p.lno_g + wc * 192 + j * 16 + g * 4);
+                const f32x4 bt = *reinterpret_cast<const f32x4*>(p.lno_b + wc * 192 + j * 16 + g * 4);
+                const f32x4 v = acc[j][i];
+                const t4 o = {from_f32<T>((v[0] - mean) * inv_std * gm[0] + bt[0]), from_f32<T>((v[1] - mean) * inv_std * gm[1] + bt[1]),
+                              from_f32<T>((v[2] - mean) * inv_std * gm[2] + bt[2]), from_f32<T>((v[3] - mean) * inv_std * gm[3] + bt[3])};
+                *reinterpret_cast<t4*>(scr + (i * 16 + r16) * PITCH + (j * 16 + g * 4) * 2) = o;
+            }
+        }
+        // this wave's 32 x 192 tile, read back as whole 16-byte chunks of consecutive columns: 24 chunks per row, 768 in all
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        T* Lb = (T*)p.lno_out + (size_t)bz * p.strideC;
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {
+            const int c = it * 64 + lane, row = c / 24, col = c - row * 24;
+            const t8 v8 = *reinterpret_cast<const t8*>(scr + row * PITCH + col * 16);
+            const int m = m0 + wr * 32 + row;
+            if (m < p.M) *reinterpret_cast<t8*>(Lb + (size_t)m * p.ldc + wc * 192 + col * 8) = v8;
+        }
+    }
+}
+static bool fullrow_ok(int operand_bytes, const GemmParams& p) {
+    static const bool off = wm_env("WM_GEMM_NO_FULLROW") != nullptr || wm_env("WM_GEMM_DIRECT") != nullptr;
+    return operand_bytes == 2 && !off && p.N == 384 && (p.K & 63) == 0 && p.group_n == 0 && !p.ln_g;
+}
+bool gemm_nt_fuses_layernorm_out(int operand_bytes, const GemmParams& p) {
+    static const bool off = wm_env("WM_GEMM_NO_LN_OUT") != nullptr;
+    return !off && fullrow_ok(operand_bytes, p);
+}
+template <typename T> static void launch_fullrow(const GemmParams& p, int batch, hipStream_t st) {
+    const int lds = 4 * 512 * 32 * (int)sizeof(T);  // 128 KB: one workgroup per CU
+    dim3 grid((p.M + 127) / 128, batch);
+    if (p.lno_out) {
+        (void)ensure_dyn_lds(&gemm_nt_fullrow_kernel<T, true>, lds);  // per device; a failure surfaces through hipGetLastError
+        hipLaunchKernelGGL((gemm_nt_fullrow_kernel<T, true>), grid, dim3(512), lds, st, p);
+    } else {
+        (void)ensure_dyn_lds(&gemm_nt_fullrow_kernel<T, false>, lds);
+        hipLaunchKernelGGL((gemm_nt_fullrow_kernel<T, false>), grid, dim3(512), lds, st, p);
+    }
+}
+
 template <typename T, typename TO> void launch_gemm_nt(const GemmParams& p, int batch, hipStream_t st) {
     if (p.ln_g && !rowpanel_ok((int)sizeof(T), p, batch)) {  // caller bug (see gemm_nt_fuses_layernorm): refuse rather than multiply un-normalised rows
         fprintf(stderr, "[whispermi] gemm_nt: fused LayerNorm asked of a shape only the plain kernels take - launch skipped\n");
+        return;
+    }
+    if constexpr (sizeof(T) == 2 && sizeof(TO) == 4) {
+        if (fullrow_ok(2, p)) return launch_fullrow<T>(p, batch, st);
+    }
+    if (p.lno_out) {
+        fprintf(stderr, "[whispermi] gemm_nt: fused output LayerNorm asked of a shape the full-row kernel does not take - launch skipped\n");
         return;
     }
     dim3 grid(p.N / 128, (p.M + 127) / 128, batch);

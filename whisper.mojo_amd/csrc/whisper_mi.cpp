@@ -867,6 +867,8 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
     for (int c0 = 0; c0 < B; c0 += s->Bc) {
         const int bc = std::min(s->Bc, B - c0);
         const int M = (int)(bc * NT);
+        const int opb = T == WM_F32 ? 4 : 2;
+        bool xn_is_ln1 = false;  // xn holds LN1(x) of the coming block, written by the epilogue of the GEMM that produced x
         DISPATCH_DT(T, TT, launch_mel_transpose_pad<TT>(mel_dev + (size_t)c0 * c.n_mels * L, s->mel_t.p, bc, c.n_mels, (int)L, m->Cp, st));
         {  // conv1 + GELU -> h1 rows 1..L (token-major)   whisper.mojo:73-75
             GemmParams p{};
@@ -903,6 +905,12 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
             p.act = 1;
             p.gelu_mode = m->cfg.gelu_mode;
             p.pos = m->enc_pos.as<float>();
+            if (gemm_nt_fuses_layernorm_out(opb, p)) {  // the first block's LN1 rides conv2's epilogue
+                p.lno_g = m->enc[0].ln1_g.as<float>();
+                p.lno_b = m->enc[0].ln1_b.as<float>();
+                p.lno_out = s->xn.p;
+                xn_is_ln1 = true;
+            }
             gemm_dispatch(T, WM_F32, p, bc, st);
         }
         for (int l = 0; l < c.n_layers; ++l) {  // layers.mojo:435-519 with is_decoder=False
@@ -918,7 +926,10 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
             p.ldw = d;
             p.ldc = 3 * d;
             p.bias = w.qkv_b.as<float>();
-            ln_then_gemm(T, T, p, s->x.as<float>(), w.ln1_g.as<float>(), w.ln1_b.as<float>(), st);
+            if (xn_is_ln1)  // the producer of x wrote LN1(x) next to it
+                gemm_dispatch(T, T, p, 1, st);
+            else
+                ln_then_gemm(T, T, p, s->x.as<float>(), w.ln1_g.as<float>(), w.ln1_b.as<float>(), st);
             DISPATCH_DT(T, TT, launch_flash_attn_enc<TT>(s->qkv.p, s->ao.p, bc, c.n_heads, c.n_audio_ctx, scale, st));
             GemmParams o{};
             o.A = s->ao.p;
@@ -933,6 +944,12 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
             o.bias = w.o_b.as<float>();
             o.residual = s->x.as<float>();
             o.ldr = d;
+            const bool xn_is_ln2 = gemm_nt_fuses_layernorm_out(opb, o);
+            if (xn_is_ln2) {
+                o.lno_g = w.ln2_g.as<float>();
+                o.lno_b = w.ln2_b.as<float>();
+                o.lno_out = s->xn.p;
+            }
             gemm_dispatch(T, WM_F32, o, 1, st);
             GemmParams f1{};
             f1.A = s->xn.p;
@@ -947,7 +964,10 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
             f1.bias = w.fc1_b.as<float>();
             f1.act = 1;
             f1.gelu_mode = m->cfg.gelu_mode;
-            ln_then_gemm(T, T, f1, s->x.as<float>(), w.ln2_g.as<float>(), w.ln2_b.as<float>(), st);
+            if (xn_is_ln2)
+                gemm_dispatch(T, T, f1, 1, st);
+            else
+                ln_then_gemm(T, T, f1, s->x.as<float>(), w.ln2_g.as<float>(), w.ln2_b.as<float>(), st);
             GemmParams f2{};
             f2.A = s->hid.p;
             f2.W = w.fc2_w.p;
@@ -961,6 +981,12 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
             f2.bias = w.fc2_b.as<float>();
             f2.residual = s->x.as<float>();
             f2.ldr = d;
+            xn_is_ln1 = l + 1 < c.n_layers && gemm_nt_fuses_layernorm_out(opb, f2);
+            if (xn_is_ln1) {  // the next block's LN1
+                f2.lno_g = m->enc[l + 1].ln1_g.as<float>();
+                f2.lno_b = m->enc[l + 1].ln1_b.as<float>();
+                f2.lno_out = s->xn.p;
+            }
             gemm_dispatch(T, WM_F32, f2, 1, st);
         }
         float* encf = s->enc_f.as<float>() + (size_t)c0 * NT * d;

@@ -58,7 +58,13 @@ struct GemmParams {
     // stream [M][lda] and the operand is LN(A) * ln_g + ln_b rounded to T, exactly what layernorm_rows + a plain GEMM compute
     const float* ln_g;
     const float* ln_b;
+    // LayerNorm of the OUTPUT rows fused into the epilogue (full-row kernel only — ask gemm_nt_fuses_layernorm_out first): besides
+    // C the kernel writes LN(C) * lno_g + lno_b as 16-bit operands to lno_out, laid out like C (ldc, strideC): the next GEMM's A
+    const float* lno_g;
+    const float* lno_b;
+    void* lno_out;
 };
+bool gemm_nt_fuses_layernorm_out(int operand_bytes, const GemmParams& p);
 // true when launch_gemm_nt<T, *> takes the A-stationary row-panel kernel for these parameters (the only one that can fuse a LayerNorm)
 bool gemm_nt_fuses_layernorm(int operand_bytes, const GemmParams& p, int batch);
 template <typename T> void launch_mel_transpose_pad(const float* mel, void* out, int B, int C, int L, int Cp, hipStream_t st);
