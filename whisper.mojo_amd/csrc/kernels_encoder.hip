@@ -511,166 +511,210 @@ bool gemm_nt_fuses_layernorm(int operand_bytes, const GemmParams& p, int batch) 
 
 // ------------------------------------------------------------------------------------------------------------
 // Full-row GEMM for the residual-stream writers (O-proj, fc2, conv2: N = 384, fp32 out): one workgroup owns 128 COMPLETE output
-// rows, so (a) the A rows are staged once instead of once per 128-column tile, (b) a barrier covers 24 MFMAs per wave on a
-// 32-deep stage of 32 KB ([A 128 rows ; W 384 rows] x 32 k) instead of 32 per 64-deep stage of 32 KB for a third of the
-// columns, and (c) the epilogue holds whole rows: it can write the NEXT LayerNorm's 16-bit operand rows next to the fp32
-// residual stream (no LayerNorm launch, no second read of the 147 MB stream).
-// 512 threads: wave (wr, wc) = rows 32 wr .. +32, columns 192 wc .. +192 (96 accumulator registers).  Stages go
-// global -> LDS by global_load_lds into a 4-slot ring, three stages ahead, counted vmcnt + raw s_barrier (as the row-panel
-// kernel).  LDS rows are 64 B; the 16-byte chunk g of row r lives at position g ^ (-(r >> 2) & 3): with ds_read_b128's lane
-// groups ({0-3, 12-15, 20-27}, ...) the four (row group, g) pairs of a group then take the four chunk positions once each.
+// rows.  (a) The A rows are staged once, not once per 128-column tile, and W once per 128 rows of ALL columns: 1.18 GB through
+// L2 -> LDS for fc2 at 64 clips against 1.77 GB with 128x128 tiles — that traffic, not MFMA or HBM, is what bounds these GEMMs.
+// (b) The epilogue holds whole rows: it can write the NEXT LayerNorm's 16-bit operand rows beside the fp32 residual stream
+// (no LayerNorm launch, no second read of the 147 MB stream).
+// 512 threads: wave (wr, wc) = rows 64 wr .. +64 (4 row blocks) x 6 column blocks of 16: blocks 2 wc, 2 wc + 1 of the first
+// 128 columns and 4 wc .. 4 wc + 3 of the other 256 (96 accumulator registers; 20 fragment reads per 48 MFMAs).
+// K advances 64 per pair of 32-KB HALF-STAGES of 256 rows x 128 B:
+//   X(t) = [A rows 0..127 ; W rows 0..127] x k64(t)      Y(t) = [W rows 128..383] x k64(t)
+// (whole 128-byte lines per row: with 64-byte rows every line travelled L2 -> L1 twice).  Half-stages go global -> LDS by
+// global_load_lds into a 4-slot ring, three ahead, counted vmcnt + raw s_barrier; 16-byte chunk c of row r sits at position
+// c ^ (r & 7) (as the 128x128 kernel).  Software pipeline with explicit fragment sets; reads and lgkmcnt waits are inline asm
+// (hipcc's wait insertion cannot express "all but the N youngest reads" across the back edge and waits for everything):
+//   step X(t): barrier; refill; request the 8 fragments of Y(t); wait until X(t)'s 12 are in; 16 MFMAs
+//   step Y(t): barrier; refill; request the 12 fragments of X(t+1); wait until Y(t)'s 8 are in; 32 MFMAs (A fragments of X(t) kept)
+// At every barrier each wave holds the previous half-stage in registers, so the slot before it is free for the refill.
 template <typename T, bool LNO>
 __global__ __launch_bounds__(512) void gemm_nt_fullrow_kernel(GemmParams p) {
-    constexpr int NSLOT = 4, SLOT = 512 * 32;  // elements per ring slot
+    constexpr int NSLOT = 4, SLOT = 256 * 64;  // elements per ring slot (32 KB)
     extern __shared__ __attribute__((aligned(16))) unsigned char fr_smem[];
     T* ring = reinterpret_cast<T*>(fr_smem);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r16 = lane & 15, g = lane >> 4;
-    const int wr = w >> 1, wc = w & 1;
+    const int wr = w >> 2, wc = w & 3;
     const int bz = blockIdx.y, m0 = blockIdx.x * 128;
-    const T* A = (const T*)p.A + (size_t)bz * p.strideA;
-    const T* W = (const T*)p.W;
-    f32x4 acc[12][2];
+    auto colj = [&](int j) { return j < 2 ? (wc * 2 + j) * 16 : 128 + (wc * 4 + j - 2) * 16; };  // first column of block j
+    f32x4 acc[6][4];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-        acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // DMA sources: 32 one-KiB pieces per stage (16 rows x 64 B each); wave w stages pieces 4w .. 4w+3 — waves 0-1 the A rows
-    const T* src[4];
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // DMA sources as (uniform base) + (32-bit byte offset per lane).  32 one-KiB pieces per half-stage (8 rows x 128 B); wave w
+    // stages pieces 4w .. 4w+3 = slot rows 32w .. 32w+31.  X: slot rows 0-127 are A rows (waves 0-3), 128-255 W rows 0-127
+    // (waves 4-7);  Y: slot row r is W row 128 + r.
+    const int l8 = lane >> 3, cch = (lane & 7) ^ l8;  // row inside a piece; logical 16-byte chunk that lives at position lane & 7
+    const char* baseW = reinterpret_cast<const char*>(p.W);
+    const char* baseX = w < 4 ? reinterpret_cast<const char*>((const T*)p.A + (size_t)bz * p.strideA) : baseW;
+    unsigned offX[4], offY;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int row = 16 * (w * 4 + j) + (lane >> 2), pos = lane & 3;
-        const int c = pos ^ ((4 - ((row >> 2) & 3)) & 3);
-        if (w < 2) {
-            int ar = m0 + row;
+        if (w < 4) {
+            int ar = m0 + 32 * w + 8 * j + l8;  // rows past M (last panel) clamp to the last row
             ar = ar < p.M ? ar : p.M - 1;
-            src[j] = A + (size_t)ar * p.lda + c * 8;
+            offX[j] = (unsigned)(((size_t)ar * p.lda + cch * 8) * sizeof(T));
         } else {
-            src[j] = W + (size_t)(row - 128) * p.ldw + c * 8;
+            offX[j] = (unsigned)(((size_t)(32 * (w - 4) + 8 * j + l8) * p.ldw + cch * 8) * sizeof(T));
         }
     }
-    const int n_stage = p.K >> 5;
-    auto issue = [&](int s) {
-        T* slot = ring + (s & (NSLOT - 1)) * SLOT + w * 4 * 512;
+    offY = (unsigned)(((size_t)(128 + 32 * w + l8) * p.ldw + cch * 8) * sizeof(T));
+    const unsigned stepY = (unsigned)(8 * p.ldw * sizeof(T));
+    const int n_half = p.K >> 5;  // two half-stages per 64 k; K % 128 == 0 (launcher), so n_half % 4 == 0
+    auto issue = [&](int h) {     // half-stage h -> slot h % 4
+        T* slot = ring + (h & (NSLOT - 1)) * SLOT + w * 4 * 512;
+        const unsigned k0 = (unsigned)((h >> 1) * 64 * sizeof(T));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + s * 32),
+        for (int j = 0; j < 4; ++j) {
+            const char* g = (h & 1) ? baseW + (offY + j * stepY + k0) : baseX + (offX[j] + k0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(slot + j * 512), 16, 0, 0);
+        }
     };
 #pragma unroll
-    for (int s = 0; s < NSLOT - 1; ++s)
-        if (s < n_stage) issue(s);
-    const int pofs = (g ^ ((4 - (r16 >> 2)) & 3)) << 3;  // every fragment row is r16 (mod 16)
-    // Software pipeline over stages with two fragment sets: step s multiplies the fragments of stage s (read from LDS during
-    // step s-1) while the 14 fragments of stage s+1 are being read — with one workgroup per CU and every wave on the same
-    // barrier nothing else covers the LDS latency.  The fragment reads and their waits are inline asm: hipcc's own wait
-    // insertion cannot express "all but the 14 youngest LDS reads" across the loop's back edge and puts lgkmcnt(0) in front of
-    // the first MFMA, i.e. waits for the reads just issued.  Protocol per step s:
-    //   top   s_waitcnt vmcnt(4|0): stage s+1 has landed (at most the one younger stage, 4 DMAs of this wave's, outstanding);
-    //         s_barrier: every wave is past the lgkmcnt wait of step s-1, i.e. holds stage s-1 AND s in registers, so slot
-    //         (s-1) % 4 is free: the DMAs of stage s+3 go there
-    //   then  14 ds_read_b128 of stage s+1 -> the other register set;  s_waitcnt lgkmcnt(14) (LDS returns in order: everything
-    //         but those 14 is complete, so stage s is in registers);  24 MFMAs on stage s.
+    for (int h = 0; h < NSLOT - 1; ++h) issue(h);  // n_half >= 4
     typedef __attribute__((ext_vector_type(4))) int i32x4;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)fr_smem;
-    const unsigned offA = lds0 + (unsigned)(((wr * 32 + r16) * 32 + pofs) * sizeof(T));
-    const unsigned offW = lds0 + (unsigned)(((128 + wc * 192 + r16) * 32 + pofs) * sizeof(T));
-    auto read_frags = [&](int s, i32x4(&a)[2], i32x4(&bf)[12]) {
-        const unsigned so = (unsigned)(s & (NSLOT - 1)) * (unsigned)(SLOT * sizeof(T));
-        const unsigned pa = offA + so, pw = offW + so;
+    // fragment byte addresses inside a slot: row R (== r16 mod 16), k-half kh: R*128 + (((kh*4 + g) ^ (R & 7)) << 4)
+    const unsigned sw0 = (unsigned)((g ^ (r16 & 7)) << 4), sw1 = (unsigned)(((4 + g) ^ (r16 & 7)) << 4);
+    const unsigned rA0 = lds0 + (unsigned)((wr * 64 + r16) * 128) + sw0, rA1 = rA0 - sw0 + sw1;           // X: A row blocks (+2048 i)
+    const unsigned rX0 = lds0 + (unsigned)((128 + wc * 32 + r16) * 128) + sw0, rX1 = rX0 - sw0 + sw1;   // X: W blocks j = 0, 1
+    const unsigned rY0 = lds0 + (unsigned)((wc * 64 + r16) * 128) + sw0, rY1 = rY0 - sw0 + sw1;          // Y: W blocks j = 2..5
+    auto slot_off = [&](int h) { return (unsigned)(h & (NSLOT - 1)) * (unsigned)(SLOT * sizeof(T)); };
+    // X fragments: a[2 i + kh] (8), wx[2 j + kh] (4);  Y fragments: wy[2 j + kh] (8)
+    auto read_x = [&](int h, i32x4(&a)[8], i32x4(&wx)[4]) {
+        const unsigned so = slot_off(h);
+        const unsigned pa0 = rA0 + so, pa1 = rA1 + so, pw0 = rX0 + so, pw1 = rX1 + so;
         asm volatile(
-            "ds_read_b128 %0, %14\n\tds_read_b128 %1, %14 offset:1024\n\t"
-            "ds_read_b128 %2, %15\n\tds_read_b128 %3, %15 offset:1024\n\tds_read_b128 %4, %15 offset:2048\n\t"
-            "ds_read_b128 %5, %15 offset:3072\n\tds_read_b128 %6, %15 offset:4096\n\tds_read_b128 %7, %15 offset:5120\n\t"
-            "ds_read_b128 %8, %15 offset:6144\n\tds_read_b128 %9, %15 offset:7168\n\tds_read_b128 %10, %15 offset:8192\n\t"
-            "ds_read_b128 %11, %15 offset:9216\n\tds_read_b128 %12, %15 offset:10240\n\tds_read_b128 %13, %15 offset:11264"
-            : "=&v"(a[0]), "=&v"(a[1]), "=&v"(bf[0]), "=&v"(bf[1]), "=&v"(bf[2]), "=&v"(bf[3]), "=&v"(bf[4]), "=&v"(bf[5]),
-              "=&v"(bf[6]), "=&v"(bf[7]), "=&v"(bf[8]), "=&v"(bf[9]), "=&v"(bf[10]), "=&v"(bf[11])
-            : "v"(pa), "v"(pw)
+            "ds_read_b128 %0, %12\n\tds_read_b128 %1, %13\n\tds_read_b128 %2, %12 offset:2048\n\tds_read_b128 %3, %13 offset:2048\n\t"
+            "ds_read_b128 %4, %12 offset:4096\n\tds_read_b128 %5, %13 offset:4096\n\tds_read_b128 %6, %12 offset:6144\n\t"
+            "ds_read_b128 %7, %13 offset:6144\n\t"
+            "ds_read_b128 %8, %14\n\tds_read_b128 %9, %15\n\tds_read_b128 %10, %14 offset:2048\n\tds_read_b128 %11, %15 offset:2048"
+            : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7]), "=&v"(wx[0]),
+              "=&v"(wx[1]), "=&v"(wx[2]), "=&v"(wx[3])
+            : "v"(pa0), "v"(pa1), "v"(pw0), "v"(pw1)
             : "memory");
     };
-#define WM_FR_HOLD(A, B)                                                                                                              \
-    "+v"(A[0]), "+v"(A[1]), "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]), "+v"(B[4]), "+v"(B[5]), "+v"(B[6]), "+v"(B[7]), "+v"(B[8]), \
-        "+v"(B[9]), "+v"(B[10]), "+v"(B[11])
-    auto mfmas = [&](const i32x4(&a)[2], const i32x4(&bf)[12]) {
-        Frag<T> fa[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i].v = __builtin_bit_cast(decltype(fa[i].v), a[i]);
-#pragma unroll
-        for (int j = 0; j < 12; ++j) {
-            Frag<T> fb;
-            fb.v = __builtin_bit_cast(decltype(fb.v), bf[j]);
-            acc[j][0] = mma32(fb, fa[0], acc[j][0]);
-            acc[j][1] = mma32(fb, fa[1], acc[j][1]);
-        }
+    auto read_y = [&](int h, i32x4(&wy)[8]) {
+        const unsigned so = slot_off(h);
+        const unsigned p0 = rY0 + so, p1 = rY1 + so;
+        asm volatile(
+            "ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %8 offset:2048\n\tds_read_b128 %3, %9 offset:2048\n\t"
+            "ds_read_b128 %4, %8 offset:4096\n\tds_read_b128 %5, %9 offset:4096\n\tds_read_b128 %6, %8 offset:6144\n\t"
+            "ds_read_b128 %7, %9 offset:6144"
+            : "=&v"(wy[0]), "=&v"(wy[1]), "=&v"(wy[2]), "=&v"(wy[3]), "=&v"(wy[4]), "=&v"(wy[5]), "=&v"(wy[6]), "=&v"(wy[7])
+            : "v"(p0), "v"(p1)
+            : "memory");
     };
-    auto step = [&](int st, i32x4(&ac)[2], i32x4(&bc)[12], i32x4(&an)[2], i32x4(&bn)[12], auto YOUNGER, auto REFILL) {
+#define WM_FR_HOLD_X(A_, W_) \
+    "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]), "+v"(A_[3]), "+v"(A_[4]), "+v"(A_[5]), "+v"(A_[6]), "+v"(A_[7]), "+v"(W_[0]), "+v"(W_[1]), "+v"(W_[2]), "+v"(W_[3])
+#define WM_FR_HOLD_Y(W_) "+v"(W_[0]), "+v"(W_[1]), "+v"(W_[2]), "+v"(W_[3]), "+v"(W_[4]), "+v"(W_[5]), "+v"(W_[6]), "+v"(W_[7])
+    auto frag = [&](const i32x4& v) {
+        Frag<T> f;
+        f.v = __builtin_bit_cast(decltype(f.v), v);
+        return f;
+    };
+    auto mfma_x = [&](const i32x4(&a)[8], const i32x4(&wx)[4]) {
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][i] = mma32(frag(wx[2 * j + kh]), frag(a[2 * i + kh]), acc[j][i]);
+    };
+    auto mfma_y = [&](const i32x4(&a)[8], const i32x4(&wy)[8]) {
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[2 + j][i] = mma32(frag(wy[2 * j + kh]), frag(a[2 * i + kh]), acc[2 + j][i]);
+    };
+#define WM_FR_TOP(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory")
+    i32x4 a0[8], a1[8], wx[4], wy[8];
+    // step X(h): fragments of X(h) are in (ac, wx) [requested during the previous step]; requests Y(h+1) into wy
+    auto step_x = [&](int h, i32x4(&ac)[8], auto YOUNGER, auto REFILL) {
         if constexpr (decltype(YOUNGER)::value)
-            asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            WM_FR_TOP(4);
         else
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if constexpr (decltype(REFILL)::value) issue(st + NSLOT - 1);
-        read_frags(st + 1, an, bn);
-        asm volatile("s_waitcnt lgkmcnt(14)" : WM_FR_HOLD(ac, bc)::"memory");
-        mfmas(ac, bc);
+            WM_FR_TOP(0);
+        if constexpr (decltype(REFILL)::value) issue(h + NSLOT - 1);
+        read_y(h + 1, wy);
+        asm volatile("s_waitcnt lgkmcnt(8)" : WM_FR_HOLD_X(ac, wx)::"memory");
+        mfma_x(ac, wx);
+        __builtin_amdgcn_sched_barrier(0);  // or the next step's wait + barrier is hoisted above these MFMAs (they touch no memory)
     };
-    i32x4 a0[2], b0[12], a1[2], b1[12];
-    if (n_stage >= 4)
-        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");  // n_stage == 2 (K = 64)
-    read_frags(0, a0, b0);
-    // n_stage is even (launcher: K % 64 == 0).  Straight-line steady state (one wait constant, unconditional refills), then the
-    // last four stages with their shorter queues.
-    int s = 0;
-    for (; s + 6 <= n_stage; s += 2) {
-        step(s, a0, b0, a1, b1, std::true_type{}, std::true_type{});
-        step(s + 1, a1, b1, a0, b0, std::true_type{}, std::true_type{});
+    // step Y(h): fragments of Y(h) are in wy, the A fragments of its k64 in ac; requests X(h+1) into (an, wx) unless LAST
+    auto step_y = [&](int h, i32x4(&ac)[8], i32x4(&an)[8], auto YOUNGER, auto REFILL, auto LAST) {
+        if constexpr (!decltype(LAST)::value) {
+            if constexpr (decltype(YOUNGER)::value)
+                WM_FR_TOP(4);
+            else
+                WM_FR_TOP(0);
+            if constexpr (decltype(REFILL)::value) issue(h + NSLOT - 1);
+            read_x(h + 1, an, wx);
+            asm volatile("s_waitcnt lgkmcnt(12)" : WM_FR_HOLD_Y(wy)::"memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : WM_FR_HOLD_Y(wy)::"memory");
+        }
+        mfma_y(ac, wy);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using Y = std::true_type;
+    using N = std::false_type;
+    WM_FR_TOP(8);  // half-stage 0 has landed (1 and 2 may be in flight)
+    read_x(0, a0, wx);
+    // steady state: groups of four half-stages (two k64), every wait the same constant and every refill unconditional; then the
+    // last group with its shorter queues.  Before the top of step h the DMAs outstanding are those of half-stages h+1 and h+2.
+    int h = 0;
+    for (; h + 8 <= n_half; h += 4) {
+        step_x(h, a0, Y{}, Y{});
+        step_y(h + 1, a0, a1, Y{}, Y{}, N{});
+        step_x(h + 2, a1, Y{}, Y{});
+        step_y(h + 3, a1, a0, Y{}, Y{}, N{});
     }
-    if (n_stage >= 4) {  // s == n_stage - 4
-        step(s, a0, b0, a1, b1, std::true_type{}, std::true_type{});
-        step(s + 1, a1, b1, a0, b0, std::true_type{}, std::false_type{});
-        s += 2;
-    }
-    step(s, a0, b0, a1, b1, std::false_type{}, std::false_type{});  // s == n_stage - 2
-    asm volatile("s_waitcnt lgkmcnt(0)" : WM_FR_HOLD(a1, b1)::"memory");
-    mfmas(a1, b1);
-#undef WM_FR_HOLD
-    // epilogue: acc[j][i][r] = C[m0 + 32 wr + 16 i + r16][192 wc + 16 j + 4 g + r];  out = act(acc) + pos + residual
+    step_x(h, a0, Y{}, Y{});               // h == n_half - 4: the refill is half-stage n_half - 1
+    step_y(h + 1, a0, a1, Y{}, N{}, N{});  // needs n_half - 2 landed; n_half - 1 may be in flight
+    step_x(h + 2, a1, N{}, N{});           // needs n_half - 1 landed
+    step_y(h + 3, a1, a0, N{}, N{}, Y{});
+#undef WM_FR_TOP
+#undef WM_FR_HOLD_X
+#undef WM_FR_HOLD_Y
+    // epilogue: acc[j][i][r] = C[m0 + 64 wr + 16 i + r16][colj(j) + 4 g + r];  out = act(acc + bias) + pos + residual
     float* Cb = (float*)p.C + (size_t)bz * p.strideC;
-    float sm[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
+    float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bv[6];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wr * 32 + i * 16 + r16;
+    for (int j = 0; j < 6; ++j) bv[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + colj(j) + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wr * 64 + i * 16 + r16;
         const bool valid = m < p.M;
         const int ml = valid ? m : p.M - 1;
-        f32x4 ex[12], bv[12];
+        f32x4 ex[6];
 #pragma unroll
-        for (int j = 0; j < 12; ++j) {
-            ex[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            bv[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + wc * 192 + j * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int j = 0; j < 6; ++j) ex[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (p.residual) {
-            const float* rr = p.residual + (size_t)bz * p.strideR + (size_t)ml * p.ldr + wc * 192 + g * 4;
+            const float* rr = p.residual + (size_t)bz * p.strideR + (size_t)ml * p.ldr + g * 4;
 #pragma unroll
-            for (int j = 0; j < 12; ++j) ex[j] = *reinterpret_cast<const f32x4*>(rr + j * 16);
+            for (int j = 0; j < 6; ++j) ex[j] = *reinterpret_cast<const f32x4*>(rr + colj(j));
         }
         if (p.pos) {
-            const float* pr = p.pos + (size_t)ml * p.N + wc * 192 + g * 4;
+            const float* pr = p.pos + (size_t)ml * p.N + g * 4;
 #pragma unroll
-            for (int j = 0; j < 12; ++j) ex[j] += *reinterpret_cast<const f32x4*>(pr + j * 16);
+            for (int j = 0; j < 6; ++j) ex[j] += *reinterpret_cast<const f32x4*>(pr + colj(j));
         }
-        float* crow = Cb + (size_t)ml * p.ldc + wc * 192 + g * 4;
+        float* crow = Cb + (size_t)ml * p.ldc + g * 4;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) {
+        for (int j = 0; j < 6; ++j) {
             f32x4 v = acc[j][i] + bv[j];
             if (p.act) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r], p.gelu_mode);
             }
             v += ex[j];
-            if (valid) *reinterpret_cast<f32x4*>(crow + j * 16) = v;
+            if (valid) *reinterpret_cast<f32x4*>(crow + colj(j)) = v;
             if constexpr (LNO) {
                 acc[j][i] = v;
 #pragma unroll
@@ -682,14 +726,13 @@ __global__ __launch_bounds__(512) void gemm_nt_fullrow_kernel(GemmParams p) {
         }
     }
     if constexpr (LNO) {
-        // LayerNorm of the finished rows (one-pass variance, whisper_tensor.mojo:249-285).  A row's 384 columns sit in 2 waves x 4
-        // lanes: butterfly over the lanes, the two column halves meet in LDS (the ring is free: the loop's last barrier plus this
-        // one mean every wave has read its last fragment).
-        constexpr int PITCH = 400;  // bytes per scratch row (384 + 16: 100 dwords, 36 mod 64 — 16 rows' 8-byte stores on distinct banks)
-        float* s_stat = reinterpret_cast<float*>(fr_smem + 8 * 32 * PITCH);  // [128 rows][2 halves][2]
-        unsigned char* scr = fr_smem + w * 32 * PITCH;
+        // LayerNorm of the finished rows (one-pass variance, whisper_tensor.mojo:249-285).  A row's 384 columns sit in 4 waves x 4
+        // lanes: butterfly over the lanes, the four waves meet in LDS (the ring is free once every wave is past its last read).
+        constexpr int PITCH = 208;  // bytes per scratch row (192 + 16: 52 dwords — 16 rows' 8-byte stores on distinct bank pairs)
+        float* s_stat = reinterpret_cast<float*>(fr_smem + 8 * 64 * PITCH);  // [128 rows][4 waves][2]
+        unsigned char* scr = fr_smem + w * 64 * PITCH;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 4; ++i) {
             sm[i] += __shfl_xor(sm[i], 16, 64);
             sq[i] += __shfl_xor(sq[i], 16, 64);
             sm[i] += __shfl_xor(sm[i], 32, 64);
@@ -698,8 +741,8 @@ __global__ __launch_bounds__(512) void gemm_nt_fullrow_kernel(GemmParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (g == 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                float* st = s_stat + ((wr * 32 + i * 16 + r16) * 2 + wc) * 2;
+            for (int i = 0; i < 4; ++i) {
+                float* st = s_stat + ((wr * 64 + i * 16 + r16) * 4 + wc) * 2;
                 st[0] = sm[i];
                 st[1] = sq[i];
             }
@@ -707,45 +750,52 @@ __global__ __launch_bounds__(512) void gemm_nt_fullrow_kernel(GemmParams p) {
         __syncthreads();
         typedef __attribute__((ext_vector_type(4))) T t4;
         typedef __attribute__((ext_vector_type(8))) T t8;
+        f32x4 gm[6], bt[6];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float* st = s_stat + (wr * 32 + i * 16 + r16) * 4;
-            const float s1 = st[0] + st[2], s2 = st[1] + st[3];
+        for (int j = 0; j < 6; ++j) {
+            gm[j] = *reinterpret_cast<const f32x4*>(p.lno_g + colj(j) + g * 4);
+            bt[j] = *reinterpret_cast<const f32x4*>(p.lno_b + colj(j) + g * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 s01 = *reinterpret_cast<const f32x4*>(s_stat + (wr * 64 + i * 16 + r16) * 8);
+            const f32x4 s23 = *reinterpret_cast<const f32x4*>(s_stat + (wr * 64 + i * 16 + r16) * 8 + 4);
+            const float s1 = (s01[0] + s01[2]) + (s23[0] + s23[2]), s2 = (s01[1] + s01[3]) + (s23[1] + s23[3]);
             const float mean = s1 / 384.0f;
             const float var = (s2 / 384.0f) - (mean * mean);
             const float inv_std = 1.0f / sqrtf(var + 1e-5f);
 #pragma unroll
-            for (int j = 0; j < 12; ++j) {
-                const f32x4 gm = *reinterpret_cast<const f32x4*>(p.lno_g + wc * 192 + j * 16 + g * 4);
-                const f32x4 bt = *reinterpret_cast<const f32x4*>(p.lno_b + wc * 192 + j * 16 + g * 4);
+            for (int j = 0; j < 6; ++j) {
                 const f32x4 v = acc[j][i];
-                const t4 o = {from_f32<T>((v[0] - mean) * inv_std * gm[0] + bt[0]), from_f32<T>((v[1] - mean) * inv_std * gm[1] + bt[1]),
-                              from_f32<T>((v[2] - mean) * inv_std * gm[2] + bt[2]), from_f32<T>((v[3] - mean) * inv_std * gm[3] + bt[3])};
-                *reinterpret_cast<t4*>(scr + (i * 16 + r16) * PITCH + (j * 16 + g * 4) * 2) = o;
+                const t4 o = {from_f32<T>((v[0] - mean) * inv_std * gm[j][0] + bt[j][0]), from_f32<T>((v[1] - mean) * inv_std * gm[j][1] + bt[j][1]),
+                              from_f32<T>((v[2] - mean) * inv_std * gm[j][2] + bt[j][2]), from_f32<T>((v[3] - mean) * inv_std * gm[j][3] + bt[j][3])};
+                *reinterpret_cast<t4*>(scr + (i * 16 + r16) * PITCH + (j * 16 + g * 4) * 2) = o;  // wave-local column order
             }
         }
-        // this wave's 32 x 192 tile, read back as whole 16-byte chunks of consecutive columns: 24 chunks per row, 768 in all
+        // this wave's 64 rows x 6 column blocks, read back as 16-byte chunks of consecutive columns: 12 chunks per row, 768 in all
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         T* Lb = (T*)p.lno_out + (size_t)bz * p.strideC;
 #pragma unroll
         for (int it = 0; it < 12; ++it) {
-            const int c = it * 64 + lane, row = c / 24, col = c - row * 24;
+            const int c = it * 64 + lane, row = c / 12, col = c - row * 12;  // chunk col = half col & 1 of wave-local column block col >> 1
             const t8 v8 = *reinterpret_cast<const t8*>(scr + row * PITCH + col * 16);
-            const int m = m0 + wr * 32 + row;
-            if (m < p.M) *reinterpret_cast<t8*>(Lb + (size_t)m * p.ldc + wc * 192 + col * 8) = v8;
+            const int m = m0 + wr * 64 + row;
+            const int jb = col >> 1;
+            const int gcol = (jb < 2 ? (wc * 2 + jb) * 16 : 128 + (wc * 4 + jb - 2) * 16) + (col & 1) * 8;
+            if (m < p.M) *reinterpret_cast<t8*>(Lb + (size_t)m * p.ldc + gcol) = v8;
         }
     }
 }
 static bool fullrow_ok(int operand_bytes, const GemmParams& p) {
     static const bool off = wm_env("WM_GEMM_NO_FULLROW") != nullptr || wm_env("WM_GEMM_DIRECT") != nullptr;
-    return operand_bytes == 2 && !off && p.N == 384 && (p.K & 63) == 0 && p.group_n == 0 && !p.ln_g;
+    return operand_bytes == 2 && !off && p.N == 384 && (p.K & 127) == 0 && p.group_n == 0 && !p.ln_g;
 }
 bool gemm_nt_fuses_layernorm_out(int operand_bytes, const GemmParams& p) {
     static const bool off = wm_env("WM_GEMM_NO_LN_OUT") != nullptr;
     return !off && fullrow_ok(operand_bytes, p);
 }
 template <typename T> static void launch_fullrow(const GemmParams& p, int batch, hipStream_t st) {
-    const int lds = 4 * 512 * 32 * (int)sizeof(T);  // 128 KB: one workgroup per CU
+    const int lds = 4 * 256 * 64 * (int)sizeof(T);  // 128 KB: one workgroup per CU
     dim3 grid((p.M + 127) / 128, batch);
     if (p.lno_out) {
         (void)ensure_dyn_lds(&gemm_nt_fullrow_kernel<T, true>, lds);  // per device; a failure surfaces through hipGetLastError
