@@ -263,11 +263,16 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmParams p) {
 // s_barrier: the ring never drains).  A workgroup walks a contiguous range of (panel, column tile) units, column tile
 // fastest, so a panel's A fragments are fetched by one or two workgroups.  Bias is folded into the accumulator
 // initialisation from an LDS copy (no VMEM loads inside the stream).  No residual / positional addends (launcher).
-template <typename T, typename TO, int KS /* K / 32 */, bool LNA = false /* A = fp32 rows, LayerNorm applied while loading */>
-__global__ __launch_bounds__(256, 2) void gemm_nt_rowpanel_kernel(GemmParams p, int n_units) {
-    constexpr int SPU = KS / 2;       // 64-k stages per unit
-    constexpr int NSLOT = 4;          // ring slots of 128 rows x 64 k
-    constexpr int SLOT = 128 * 64;    // elements per slot
+template <typename T, typename TO, int KS /* K / 32 */, bool LNA = false /* A = fp32 rows, LayerNorm applied while loading */,
+          int NW = 4 /* waves: 4 = 128-row panels, two workgroups per CU; 8 = 256-row panels, one per CU — every W stage then serves
+                        twice the rows: half the L2 -> LDS traffic and half the DMA instructions per MFMA */>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_nt_rowpanel_kernel(GemmParams p, int n_units) {
+    constexpr int SPU = KS / 2;                 // 64-k stages per unit
+    constexpr int NSLOT = NW == 4 ? 4 : 8;      // ring slots of 128 W rows x 64 k (16 KB)
+    constexpr int AHEAD = NW == 4 ? 3 : 5;      // stages requested ahead of the one being multiplied
+    constexpr int PR = NW * 32;                 // rows per panel
+    constexpr int PPW = 16 / NW;                // one-KiB DMA pieces per stage and wave
+    constexpr int SLOT = 128 * 64;              // elements per slot
     extern __shared__ __attribute__((aligned(16))) unsigned char rp_smem[];  // ONE LDS object: ring, then fp32 bias [N]
     T* ring = reinterpret_cast<T*>(rp_smem);
     float* s_bias = reinterpret_cast<float*>(rp_smem + (size_t)NSLOT * SLOT * sizeof(T));
@@ -277,10 +282,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_rowpanel_kernel(GemmParams p, 
     const int u0 = (int)((long)blockIdx.x * n_units / gridDim.x), u1 = (int)((long)(blockIdx.x + 1) * n_units / gridDim.x);
     const int n_stage = (u1 - u0) * SPU;
     const T* Wg = (const T*)p.W;
-    for (int i = threadIdx.x; i < p.N; i += 256) s_bias[i] = p.bias ? p.bias[i] : 0.f;
+    for (int i = threadIdx.x; i < p.N; i += NW * 64) s_bias[i] = p.bias ? p.bias[i] : 0.f;
     float* s_gb = s_bias + p.N;  // LNA: gamma [K], beta [K]
     if constexpr (LNA) {
-        for (int i = threadIdx.x; i < KS * 32; i += 256) {
+        for (int i = threadIdx.x; i < KS * 32; i += NW * 64) {
             s_gb[i] = p.ln_g[i];
             s_gb[KS * 32 + i] = p.ln_b[i];
         }
@@ -290,10 +295,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_rowpanel_kernel(GemmParams p, 
     auto issue = [&](int s) {  // stage s of this workgroup's stream -> ring slot s % 4
         const int u = u0 + s / SPU, t = s % SPU;
         const int ct = u % nct;
-        stage_tile<T>(Wg + (size_t)ct * 128 * p.ldw + t * 64, p.ldw, ring + (s & (NSLOT - 1)) * SLOT, lane, w);
+        const T* gbase = Wg + (size_t)ct * 128 * p.ldw + t * 64;
+        T* slot = ring + (s & (NSLOT - 1)) * SLOT;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {  // as stage_tile: piece i = rows 8i .. 8i+7, 16-byte chunk c of row r at position c ^ (r & 7)
+            const int i = w * PPW + j;
+            const int row = 8 * i + (lane >> 3), cp = lane & 7;
+            const T* g = gbase + (size_t)row * p.ldw + ((cp ^ (row & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(slot + i * 512), 16, 0, 0);
+        }
     };
 #pragma unroll
-    for (int s = 0; s < NSLOT - 1; ++s)
+    for (int s = 0; s < AHEAD; ++s)
         if (s < n_stage) issue(s);
 
     Frag<T> a[2][KS];
@@ -308,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_rowpanel_kernel(GemmParams p, 
             panel = pn;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                int row = pn * 128 + w * 32 + i * 16 + r16;
+                int row = pn * PR + w * 32 + i * 16 + r16;
                 row = row < p.M ? row : p.M - 1;
                 if constexpr (LNA) {
                     // The fp32 residual row instead of its normalised 16-bit copy: a lane holds 8 of every 32 columns (the four
@@ -372,34 +386,50 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_rowpanel_kernel(GemmParams p, 
             // loads, stores and LDS-DMA count together in issue order: younger than stage s are the (<= 2) stages issued
             // after it, 4 DMAs each, plus — for the first three stages after an epilogue — that epilogue's 8 or 16 stores.
             // The barrier then also says everyone is done reading slot (s-1) % 4, which the next DMA overwrites.
+            // Younger than stage s are min(AHEAD - 1, rem) stages of PPW DMAs each — 8 in the steady state for either shape —
+            // plus, while the unit's first AHEAD stages are multiplied, the previous epilogue's stores.
             const int rem = n_stage - 1 - s;
             if (t == 0 && newp) {  // fresh A fragments: the compiler waits vmcnt(0) for them anyway
                 WM_RP_WAIT(0);
-            } else if (t < 3 && st_pend) {
-                if constexpr (sizeof(TO) == 2) {  // 8 epilogue stores
-                    if (rem >= 2)
-                        WM_RP_WAIT(16);
-                    else if (rem == 1)
-                        WM_RP_WAIT(12);
+            } else if (rem >= AHEAD - 1) {
+                if (t < AHEAD && st_pend) {
+                    if constexpr (sizeof(TO) == 2)
+                        WM_RP_WAIT(16);  // 8 epilogue stores
                     else
-                        WM_RP_WAIT(8);
-                } else {  // 16 epilogue stores
-                    if (rem >= 2)
-                        WM_RP_WAIT(24);
-                    else if (rem == 1)
-                        WM_RP_WAIT(20);
-                    else
-                        WM_RP_WAIT(16);
-                }
-            } else {
-                if (rem >= 2)
+                        WM_RP_WAIT(24);  // 16 epilogue stores
+                } else {
                     WM_RP_WAIT(8);
-                else if (rem == 1)
+                }
+            } else if constexpr (NW == 4) {
+                if (t < AHEAD && st_pend) {
+                    if constexpr (sizeof(TO) == 2) {
+                        if (rem == 1)
+                            WM_RP_WAIT(12);
+                        else
+                            WM_RP_WAIT(8);
+                    } else {
+                        if (rem == 1)
+                            WM_RP_WAIT(20);
+                        else
+                            WM_RP_WAIT(16);
+                    }
+                } else {
+                    if (rem == 1)
+                        WM_RP_WAIT(4);
+                    else
+                        WM_RP_WAIT(0);
+                }
+            } else {  // the last three stages of the workgroup's whole stream: also waits for any stores (conservative)
+                if (rem == 3)
+                    WM_RP_WAIT(6);
+                else if (rem == 2)
                     WM_RP_WAIT(4);
+                else if (rem == 1)
+                    WM_RP_WAIT(2);
                 else
                     WM_RP_WAIT(0);
             }
-            if (s + NSLOT - 1 < n_stage) issue(s + NSLOT - 1);
+            if (s + AHEAD < n_stage) issue(s + AHEAD);
             const T* Ws = ring + (s & (NSLOT - 1)) * SLOT;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -434,7 +464,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_rowpanel_kernel(GemmParams p, 
             // just consumed is free until the next stage's DMA (issued after that stage's barrier); each wave takes 4 KB
             // of it = 16 rows x 256 B, written as [row][16-byte chunk ^ row] and read back 4 whole rows per instruction.
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone is done reading this slot
-            unsigned char* scr = reinterpret_cast<unsigned char*>(ring + ((s - 1) & (NSLOT - 1)) * SLOT) + w * 4096;
+            // (8 waves: 32 KB = the TWO slots behind the stream, (s-1) % 8 for waves 0-3 and (s-2) % 8 for waves 4-7 — with 5 stages
+            // requested ahead of 8 slots both stay free until the tops of stages s+2 / s+1, past this epilogue's barrier-ordered end)
+            unsigned char* scr = reinterpret_cast<unsigned char*>(ring + ((s - 1 - (w >> 2)) & (NSLOT - 1)) * SLOT) + (w & 3) * 4096;
             typedef __attribute__((ext_vector_type(4))) TO to4;
             typedef __attribute__((ext_vector_type(8))) TO to8;
 #pragma unroll
@@ -450,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_rowpanel_kernel(GemmParams p, 
                     const int chunk = (2 * j + (g >> 1)) ^ r16;
                     *reinterpret_cast<to4*>(scr + r16 * 256 + chunk * 16 + (g & 1) * 8) = o;
                 }
-                const int mbase = pn * 128 + w * 32 + i * 16;
+                const int mbase = pn * PR + w * 32 + i * 16;
                 if (mbase < p.M) {  // wave-uniform: 4 store instructions (rows past M masked per lane)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -461,11 +493,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_rowpanel_kernel(GemmParams p, 
                 }
             }
             // exactly 8 store instructions per wave when all its 32 rows exist; otherwise (last panel) drain, don't count
-            st_pend = __builtin_amdgcn_readfirstlane((int)(pn * 128 + w * 32 + 32 <= p.M)) != 0;
+            st_pend = __builtin_amdgcn_readfirstlane((int)(pn * PR + w * 32 + 32 <= p.M)) != 0;
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int m = pn * 128 + w * 32 + i * 16 + r16;
+                const int m = pn * PR + w * 32 + i * 16 + r16;
                 if (m >= p.M) continue;
                 float* crow = (float*)Cb + (size_t)m * p.ldc + ncol + g * 4;
 #pragma unroll
@@ -479,24 +511,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_rowpanel_kernel(GemmParams p, 
                 }
             }
             // exactly 16 store instructions per wave when all its 32 rows exist
-            st_pend = __builtin_amdgcn_readfirstlane((int)(pn * 128 + w * 32 + 32 <= p.M)) != 0;
+            st_pend = __builtin_amdgcn_readfirstlane((int)(pn * PR + w * 32 + 32 <= p.M)) != 0;
         }
         if (!st_pend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #undef WM_RP_WAIT
 }
+template <typename T, typename TO, int KS, bool LNA, int NW> static void launch_rowpanel_t(const GemmParams& p, hipStream_t st) {
+    const int n_units = ((p.M + NW * 32 - 1) / (NW * 32)) * (p.N / 128);
+    static const int grid_env = wm_env("WM_RP_GRID") ? atoi(wm_env("WM_RP_GRID")) : 0;
+    const int grid = std::min(n_units, grid_env > 0 ? grid_env : (NW == 4 ? 512 : 256));  // two 64-KB-ring workgroups per CU, or one of 128 KB
+    const size_t lds = (size_t)(NW == 4 ? 4 : 8) * 128 * 64 * sizeof(T) + (size_t)p.N * 4 + (LNA ? (size_t)2 * KS * 32 * 4 : 0);
+    (void)ensure_dyn_lds(&gemm_nt_rowpanel_kernel<T, TO, KS, LNA, NW>, NW == 4 ? 80 * 1024 : 144 * 1024);  // per device; a failure surfaces through hipGetLastError
+    hipLaunchKernelGGL((gemm_nt_rowpanel_kernel<T, TO, KS, LNA, NW>), dim3(grid), dim3(NW * 64), lds, st, p, n_units);
+}
 template <typename T, typename TO, int KS> static void launch_rowpanel(const GemmParams& p, hipStream_t st) {
-    const int n_units = ((p.M + 127) / 128) * (p.N / 128);
-    static const int grid_max = wm_env("WM_RP_GRID") ? atoi(wm_env("WM_RP_GRID")) : 512;  // two 64-KB-ring workgroups per CU
-    const int grid = std::min(n_units, grid_max);
-    const size_t lds = (size_t)4 * 128 * 64 * sizeof(T) + (size_t)p.N * 4 + (p.ln_g ? (size_t)2 * KS * 32 * 4 : 0);
-    if (p.ln_g) {
-        (void)ensure_dyn_lds(&gemm_nt_rowpanel_kernel<T, TO, KS, true>, 80 * 1024);
-        hipLaunchKernelGGL((gemm_nt_rowpanel_kernel<T, TO, KS, true>), dim3(grid), dim3(256), lds, st, p, n_units);
-        return;
+    // 128-row panels, two workgroups per CU.  The 8-wave shape (256-row panels: half the W traffic and DMA instructions per MFMA)
+    // measured the same on one box (encoder 4.24 vs 4.23 ms): W staging is not what bounds this kernel.  Developer A/B only.
+#ifdef WM_DEV
+    if (wm_env("WM_RP_NW8")) {
+        if (p.ln_g) return launch_rowpanel_t<T, TO, KS, true, 8>(p, st);
+        return launch_rowpanel_t<T, TO, KS, false, 8>(p, st);
     }
-    (void)ensure_dyn_lds(&gemm_nt_rowpanel_kernel<T, TO, KS>, 80 * 1024);  // per device; a failure surfaces through hipGetLastError
-    hipLaunchKernelGGL((gemm_nt_rowpanel_kernel<T, TO, KS>), dim3(grid), dim3(256), lds, st, p, n_units);
+#endif
+    if (p.ln_g) return launch_rowpanel_t<T, TO, KS, true, 4>(p, st);
+    launch_rowpanel_t<T, TO, KS, false, 4>(p, st);
 }
 static bool rowpanel_ok(int operand_bytes, const GemmParams& p, int batch) {
     // A-stationary row-panel kernel: plain [M,K]x[N,K] (no conv batching), K = 384 (K = 512 needs 128 A registers: spills), no addends, N <= 3072
