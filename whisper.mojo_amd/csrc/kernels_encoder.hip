@@ -111,8 +111,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             for (int j = 0; j < 4; ++j) {
                 f32x4 v = acc[j][i] + bv[j];
                 if (p.act) {
+                    if constexpr (FASTG) {
+                        v = gelu_fast4(v, p.gelu_mode);
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = FASTG ? gelu_fast(v[r], p.gelu_mode) : gelu_f(v[r], p.gelu_mode);
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r], p.gelu_mode);
+                    }
                 }
                 v += ex[ii][j];
                 if constexpr (sizeof(TO) == 4) {
@@ -475,8 +479,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_nt_rowpanel_kernel(GemmParams
                 for (int j = 0; j < 8; ++j) {
                     f32x4 v = acc[j][i];
                     if (p.act) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r], p.gelu_mode);
+                        v = gelu_fast4(v, p.gelu_mode);
                     }
                     const to4 o = {from_f32<TO>(v[0]), from_f32<TO>(v[1]), from_f32<TO>(v[2]), from_f32<TO>(v[3])};
                     const int chunk = (2 * j + (g >> 1)) ^ r16;
@@ -504,8 +507,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_nt_rowpanel_kernel(GemmParams
                 for (int j = 0; j < 8; ++j) {
                     f32x4 v = acc[j][i];
                     if (p.act) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r], p.gelu_mode);
+                        v = gelu_fast4(v, p.gelu_mode);
                     }
                     *reinterpret_cast<f32x4*>(crow + j * 16) = v;
                 }
@@ -749,8 +751,7 @@ __global__ __launch_bounds__(512) void gemm_nt_fullrow_kernel(GemmParams p) {
         for (int j = 0; j < 6; ++j) {
             f32x4 v = acc[j][i] + bv[j];
             if (p.act) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r], p.gelu_mode);
+                v = gelu_fast4(v, p.gelu_mode);
             }
             v += ex[j];
             if (valid) *reinterpret_cast<f32x4*>(crow + colj(j)) = v;

@@ -106,16 +106,36 @@ __device__ __forceinline__ float gelu_f(float x, int mode) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-// 16-bit operand modes: the tanh form as one exp + one reciprocal, 0.5x(1+tanh(u)) = x / (1 + exp(-2u)) — the accurate
-// tanhf costs ~40 VALU instructions per element, which made the GELU epilogue of the K=384 GEMMs longer than their
-// MFMA main loop.  Relative error ~1e-6, far below the bf16/f16 rounding of the stored result.
+// 16-bit operand modes: the tanh form as one exp2 + one reciprocal, 0.5x(1+tanh(u)) = x / (1 + exp(-2u)) with
+// -2u·log2(e) = x·(K1 + K2·x²) folded into two constants — the accurate tanhf costs ~40 VALU instructions per element, and even
+// the 9-instruction form of round 1 made fc1's GELU epilogue (147 M elements at 64 clips) cost more than its MFMA main loop.
+// Relative error ~1e-6, far below the bf16/f16 rounding of the stored result.  x -> -inf gives exp2 = inf, 1/inf = 0: -0.
 __device__ __forceinline__ float gelu_fast(float x, int mode) {
     if (mode == 0) {
-        const float SQRT_2_PI = 0.79788456f, COEFF = 0.044715f;
-        const float u = SQRT_2_PI * (x + COEFF * x * x * x);
-        return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
+        constexpr float K1 = -2.0f * 0.79788456f * 1.4426950408889634f, K2 = K1 * 0.044715f;
+        const float e = x * __builtin_fmaf(x * x, K2, K1);
+        return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(e));
     }
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+// the same on four values: the polynomial, the +1 and the final product as packed fp32 (v_pk_mul / v_pk_fma / v_pk_add)
+__device__ __forceinline__ f32x4 gelu_fast4(f32x4 x, int mode) {
+    if (mode == 0) {
+        constexpr float K1 = -2.0f * 0.79788456f * 1.4426950408889634f, K2 = K1 * 0.044715f;
+        const f32x4 k1 = f32x4{K1, K1, K1, K1}, k2 = f32x4{K2, K2, K2, K2}, one = f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 e = x * __builtin_elementwise_fma(x * x, k2, k1);
+        f32x4 d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] = __builtin_amdgcn_exp2f(e[r]);
+        d += one;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] = __builtin_amdgcn_rcpf(d[r]);
+        return x * d;
+    }
+    f32x4 y;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = gelu_fast(x[r], mode);
+    return y;
 }
 
 }  // namespace wm
