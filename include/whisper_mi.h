@@ -149,6 +149,14 @@ int wm_op_matmul_nt(float* C, const float* A, const float* B, const float* bias,
 /* layer_norm(out, inp, gamma, beta, eps)  whisper_tensor.mojo:249-285 (one-pass variance). cols % 128 == 0, <= 1024 */
 int wm_op_layer_norm(float* out, const float* inp, const float* gamma, const float* beta, int rows, int cols,
                      float eps);
+/* The MLP half of ResidualAttentionBlock.forward  layers.mojo:489-517 :  x += fc2(gelu(fc1(layer_norm(x, ln_g, ln_b)))),
+ * x [M, d] in place; fc1_w [ffn, d], fc2_w [d, ffn] (HF [out, in]).  With next_g / next_b / xn_out non-NULL also returns
+ * layer_norm(x_new, next_g, next_b) rounded to the operand dtype (what the next projection is fed) in xn_out [M, d].
+ * Runs on the encoder's own kernels: for 16-bit dtypes with d = 384 the LayerNorm rides the fc1 GEMM's A load, and the residual
+ * add and the next LayerNorm ride fc2's epilogue.  d % 128 == 0, ffn % 128 == 0. */
+int wm_op_mlp_block(float* x, const float* ln_g, const float* ln_b, const float* fc1_w, const float* fc1_b, const float* fc2_w,
+                    const float* fc2_b, const float* next_g, const float* next_b, float* xn_out, int M, int d, int ffn, int dtype,
+                    int gelu_mode);
 /* gelu(t) in place  whisper_tensor.mojo:288-308 (mode WM_GELU_TANH) */
 int wm_op_gelu(float* t, size_t n, int mode);
 /* softmax(t) rows in place  whisper_tensor.mojo:311-355 */

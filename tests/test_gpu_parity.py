@@ -107,6 +107,94 @@ def test_op_matmul_rowpanel_bf16(hip, M, N):
             assert np.array_equal(out, first)
 
 
+@pytest.mark.parametrize("M,K", [(4741, 1536), (130, 384), (1500, 1152)])
+def test_op_matmul_fullrow_bf16(hip, M, K):
+    """N = 384 with 16-bit operands and fp32 output runs on the full-row kernel (half-stage LDS ring, asm fragment pipeline,
+    ragged last panel, 6 / 18 / 24 k64 steps): exact products of the rounded operands, and the same bits every time."""
+    import torch
+    from whisper_mojo_amd import whisper_tensor as wt, DT_BF16
+    r = np.random.default_rng(M + K)
+    A, B = r.standard_normal((M, K), np.float32), r.standard_normal((384, K), np.float32)
+    bias = r.standard_normal(384, np.float32)
+    Ab = torch.from_numpy(A).bfloat16().float().numpy()
+    Bb = torch.from_numpy(B).bfloat16().float().numpy()
+    ref = Ab.astype(np.float64) @ Bb.T.astype(np.float64) + bias
+    first = None
+    for _ in range(3):
+        out = wt.Tensor(M, 384)
+        wt.matmul(out, A, B, bias, dtype=DT_BF16)
+        assert np.abs(out - ref).max() < 4e-4 * np.sqrt(K / 384.0)
+        if first is None:
+            first = out.copy()
+        else:
+            assert np.array_equal(out, first)
+
+
+def _bf16_round(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).bfloat16().float().numpy()
+
+
+def _mlp_block_ref(x, g1, b1, w1, bb1, w2, bb2, g2, b2, rnd):
+    """layers.mojo:489-517 in float64, with the operand roundings of the 16-bit path (rnd) where the kernels round: the
+    LayerNorm output fed to fc1, the hidden activations fed to fc2, the weights, and the returned next-LayerNorm rows."""
+    def ln(v, g, b):
+        v32 = v.astype(np.float32)
+        mean = v32.mean(axis=1, keepdims=True, dtype=np.float64)
+        var = (v32.astype(np.float64) ** 2).mean(axis=1, keepdims=True) - mean * mean  # one-pass variance (whisper_tensor.mojo:273)
+        return (v32 - mean) / np.sqrt(var + 1e-5) * g + b
+    xn = rnd(ln(x, g1, b1)).astype(np.float64)
+    h = xn @ rnd(w1).T.astype(np.float64) + bb1
+    h = 0.5 * h * (1.0 + np.tanh(0.79788456 * (h + 0.044715 * h ** 3)))  # whisper_tensor.mojo:288-308
+    h = rnd(h).astype(np.float64)
+    out = x.astype(np.float64) + h @ rnd(w2).T.astype(np.float64) + bb2
+    return out, ln(out, g2, b2)
+
+
+@pytest.mark.parametrize("M", [300, 4741])
+def test_op_mlp_block_bf16(hip, M):
+    """The MLP half of a block on the encoder's 16-bit kernels: LayerNorm inside the fc1 GEMM's A load, tanh-GELU epilogue,
+    fc2 on the full-row kernel with the residual add and the NEXT LayerNorm in its epilogue — against float64 with the same
+    operand roundings.  Differences left: fp32 accumulation order and single-ulp flips of rounded intermediates."""
+    from whisper_mojo_amd import whisper_tensor as wt, DT_BF16
+    r = np.random.default_rng(M)
+    d, ffn = 384, 1536
+    x = (r.standard_normal((M, d)) * 1.5 + 0.3).astype(np.float32)
+    g1, b1 = (1.0 + 0.2 * r.standard_normal(d)).astype(np.float32), (0.1 * r.standard_normal(d)).astype(np.float32)
+    g2, b2 = (1.0 + 0.2 * r.standard_normal(d)).astype(np.float32), (0.1 * r.standard_normal(d)).astype(np.float32)
+    w1, bb1 = (r.standard_normal((ffn, d)) / np.sqrt(d)).astype(np.float32), (0.1 * r.standard_normal(ffn)).astype(np.float32)
+    w2, bb2 = (r.standard_normal((d, ffn)) / np.sqrt(ffn)).astype(np.float32), (0.1 * r.standard_normal(d)).astype(np.float32)
+    ref_x, ref_xn = _mlp_block_ref(x, g1, b1, w1, bb1, w2, bb2, g2, b2, _bf16_round)
+    got = x.copy()
+    xn = wt.mlp_block(got, g1, b1, w1, bb1, w2, bb2, next_ln=(g2, b2), dtype=DT_BF16)
+    assert np.abs(got - ref_x).max() < 1e-2          # measured 1.0e-3 / 4.7e-3 (M = 300 / 4741): a bf16 ulp flip of a hidden value moves its sum
+    assert np.abs(got - ref_x).mean() < 5e-5         # measured 2e-6 / 4e-6
+    assert np.array_equal(_bf16_round(xn), xn)       # really 16-bit values
+    err = np.abs(xn - ref_xn)
+    assert err.max() < 0.04                          # one bf16 ulp at |v| < 8 (measured 0.0156: one ulp at |v| in [2, 4))
+    assert (err > 0.004 * (1 + np.abs(ref_xn))).mean() < 0.001  # measured 0: beyond half-ulp rounding only where a tie flipped
+    again = x.copy()
+    xn2 = wt.mlp_block(again, g1, b1, w1, bb1, w2, bb2, next_ln=(g2, b2), dtype=DT_BF16)
+    assert np.array_equal(again, got) and np.array_equal(xn2, xn)
+
+
+def test_op_mlp_block_fp32(hip):
+    """The same entry with exact fp32 operands (plain LayerNorm + GEMM kernels): float64 reference, no roundings."""
+    from whisper_mojo_amd import whisper_tensor as wt, DT_F32
+    r = np.random.default_rng(7)
+    M, d, ffn = 200, 384, 1536
+    x = r.standard_normal((M, d)).astype(np.float32)
+    g1, b1 = (1.0 + 0.2 * r.standard_normal(d)).astype(np.float32), (0.1 * r.standard_normal(d)).astype(np.float32)
+    g2, b2 = (1.0 + 0.2 * r.standard_normal(d)).astype(np.float32), (0.1 * r.standard_normal(d)).astype(np.float32)
+    w1, bb1 = (r.standard_normal((ffn, d)) / np.sqrt(d)).astype(np.float32), (0.1 * r.standard_normal(ffn)).astype(np.float32)
+    w2, bb2 = (r.standard_normal((d, ffn)) / np.sqrt(ffn)).astype(np.float32), (0.1 * r.standard_normal(d)).astype(np.float32)
+    ref_x, ref_xn = _mlp_block_ref(x, g1, b1, w1, bb1, w2, bb2, g2, b2, lambda a: np.asarray(a, np.float32))
+    got = x.copy()
+    xn = wt.mlp_block(got, g1, b1, w1, bb1, w2, bb2, next_ln=(g2, b2), dtype=DT_F32)
+    assert np.abs(got - ref_x).max() < 2e-5
+    assert np.abs(xn - ref_xn).max() < 5e-5
+
+
 def test_op_layer_norm(hip, oracle_mod):
     from whisper_mojo_amd import whisper_tensor as wt
     for rows, cols in ((9, 384), (1, 128), (70, 512)):

@@ -1972,6 +1972,96 @@ extern "C" int wm_op_layer_norm(float* out, const float* inp, const float* gamma
     return 0;
 }
 
+extern "C" int wm_op_mlp_block(float* x, const float* ln_g, const float* ln_b, const float* fc1_w, const float* fc1_b, const float* fc2_w,
+                               const float* fc2_b, const float* next_g, const float* next_b, float* xn_out, int M, int d, int ffn,
+                               int dtype, int gelu_mode) {
+    if (!x || !ln_g || !ln_b || !fc1_w || !fc1_b || !fc2_w || !fc2_b || M <= 0) return fail(WM_E_ARG, "bad argument");
+    if (d <= 0 || d % 128 || d > 1024 || ffn <= 0 || ffn % 128) return fail(WM_E_ARG, "d and ffn must be multiples of 128 (d <= 1024)");
+    if (dtype < 0 || dtype > 2 || (gelu_mode != 0 && gelu_mode != 1)) return fail(WM_E_ARG, "bad dtype / gelu_mode");
+    const bool want_next = next_g && next_b && xn_out;
+    if (!want_next && (next_g || next_b || xn_out)) return fail(WM_E_ARG, "next_g, next_b and xn_out go together");
+    TmpDev t;
+    t.bufs.reserve(16);
+    hipStream_t st = nullptr;
+    const size_t Mp = ((size_t)M + 127) / 128 * 128, ts = dt_size(dtype);  // the tile kernels read whole 128-row panels
+    DevBuf &dx = t.add(), &xn = t.add(), &hid = t.add(), &g1 = t.add(), &b1 = t.add(), &w1 = t.add(), &bb1 = t.add(), &w2 = t.add(),
+           &bb2 = t.add(), &g2 = t.add(), &b2 = t.add();
+    std::vector<float> xp(Mp * d, 0.f);
+    memcpy(xp.data(), x, (size_t)M * d * 4);
+    WMCHK(upload(dx, xp.data(), xp.size(), WM_F32));
+    WMCHK(xn.alloc(Mp * d * ts, true));
+    WMCHK(hid.alloc(Mp * ffn * ts, true));
+    WMCHK(upload(g1, ln_g, d, WM_F32));
+    WMCHK(upload(b1, ln_b, d, WM_F32));
+    WMCHK(upload(w1, fc1_w, (size_t)ffn * d, dtype));
+    WMCHK(upload(bb1, fc1_b, ffn, WM_F32));
+    WMCHK(upload(w2, fc2_w, (size_t)d * ffn, dtype));
+    WMCHK(upload(bb2, fc2_b, d, WM_F32));
+    if (want_next) {
+        WMCHK(upload(g2, next_g, d, WM_F32));
+        WMCHK(upload(b2, next_b, d, WM_F32));
+    }
+    GemmParams f1{};
+    f1.A = xn.p;
+    f1.W = w1.p;
+    f1.C = hid.p;
+    f1.M = M;
+    f1.N = ffn;
+    f1.K = d;
+    f1.lda = d;
+    f1.ldw = d;
+    f1.ldc = ffn;
+    f1.bias = bb1.as<float>();
+    f1.act = 1;
+    f1.gelu_mode = gelu_mode;
+    ln_then_gemm(dtype, dtype, f1, dx.as<float>(), g1.as<float>(), b1.as<float>(), st);
+    GemmParams f2{};
+    f2.A = hid.p;
+    f2.W = w2.p;
+    f2.C = dx.p;
+    f2.M = M;
+    f2.N = d;
+    f2.K = ffn;
+    f2.lda = ffn;
+    f2.ldw = ffn;
+    f2.ldc = d;
+    f2.bias = bb2.as<float>();
+    f2.residual = dx.as<float>();
+    f2.ldr = d;
+    bool fused_next = false;
+    if (want_next && gemm_nt_fuses_layernorm_out(dtype == WM_F32 ? 4 : 2, f2)) {
+        f2.lno_g = g2.as<float>();
+        f2.lno_b = b2.as<float>();
+        f2.lno_out = xn.p;
+        fused_next = true;
+    }
+    gemm_dispatch(dtype, WM_F32, f2, 1, st);
+    if (want_next && !fused_next)
+        DISPATCH_DT(dtype, TT, launch_layernorm_rows<TT>(dx.as<float>(), g2.as<float>(), b2.as<float>(), xn.p, nullptr, M, d, 1e-5f, st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(x, dx.p, (size_t)M * d * 4, hipMemcpyDeviceToHost));
+    if (want_next) {  // the operand rows as the next GEMM reads them, widened on the host
+        const size_t n = (size_t)M * d;
+        if (dtype == WM_F32) {
+            HIPCHK(hipMemcpy(xn_out, xn.p, n * 4, hipMemcpyDeviceToHost));
+        } else {
+            std::vector<uint16_t> h(n);
+            HIPCHK(hipMemcpy(h.data(), xn.p, n * 2, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < n; ++i) {
+                if (dtype == WM_BF16) {
+                    const uint32_t u = (uint32_t)h[i] << 16;
+                    memcpy(&xn_out[i], &u, 4);
+                } else {
+                    _Float16 hv;
+                    memcpy(&hv, &h[i], 2);
+                    xn_out[i] = (float)hv;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
 extern "C" int wm_op_gelu(float* tt, size_t n, int mode) {
     if (!tt || (mode != 0 && mode != 1)) return fail(WM_E_ARG, "bad argument");
     if (n == 0) return 0;

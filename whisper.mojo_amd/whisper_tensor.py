@@ -35,6 +35,25 @@ def matmul(C_out: np.ndarray, A, B, bias=None, dtype=DT_F32):
     _lib.check(_lib.lib().wm_op_matmul_nt(_fp(C_out), _fp(A), _fp(B), _fp(b), M, N, K, dtype))
 
 
+def mlp_block(x: np.ndarray, ln_g, ln_b, fc1_w, fc1_b, fc2_w, fc2_b, next_ln=None, dtype=DT_F32, gelu_mode: int = GELU_TANH):
+    """layers.mojo:489-517 (the MLP half of ResidualAttentionBlock.forward): x += fc2(gelu(fc1(layer_norm(x)))), in place.
+    next_ln = (gamma, beta): also returns layer_norm(x_new) rounded to the operand dtype — the rows the next projection reads."""
+    _chk_out(x, x.shape)
+    M, d = x.shape
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    ln_g, ln_b, fc1_w, fc1_b, fc2_w, fc2_b = f(ln_g).ravel(), f(ln_b).ravel(), f(fc1_w), f(fc1_b).ravel(), f(fc2_w), f(fc2_b).ravel()
+    ffn = fc1_w.shape[0]
+    if fc1_w.shape != (ffn, d) or fc2_w.shape != (d, ffn):
+        raise ValueError("fc1_w must be [ffn, d] and fc2_w [d, ffn]")
+    ng = nb = xn = None
+    if next_ln is not None:
+        ng, nb = f(next_ln[0]).ravel(), f(next_ln[1]).ravel()
+        xn = np.empty((M, d), np.float32)
+    _lib.check(_lib.lib().wm_op_mlp_block(_fp(x), _fp(ln_g), _fp(ln_b), _fp(fc1_w), _fp(fc1_b), _fp(fc2_w), _fp(fc2_b), _fp(ng), _fp(nb),
+                                          _fp(xn), M, d, ffn, dtype, gelu_mode))
+    return xn
+
+
 def layer_norm(out: np.ndarray, inp, gamma, beta, eps: float = 1e-5):
     """whisper_tensor.mojo:249-285"""
     x = np.ascontiguousarray(inp, np.float32)
