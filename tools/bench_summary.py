@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Reads bench.py JSON lines on stdin and prints a compact summary (developer tool)."""
-import json, sys
-for line in sys.stdin:
+"""Reads bench.py JSON lines from the files named on the command line (or stdin) and prints a compact summary (developer tool)."""
+import fileinput, json, sys
+for line in fileinput.input():
     line = line.strip()
     if not line.startswith("{"):
         continue
