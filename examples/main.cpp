@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
         } else {
             std::cout << "\n(no " << vocab << ": ids only)\n";
         }
-        std::cout << "\nDone.\n";
+        std::cout << "\nDone." << std::endl;  // flushed here: everything main printed is out before any exit-time teardown
     } catch (const std::exception& e) {
         std::cerr << "error: " << e.what() << "\n";
         return 1;
