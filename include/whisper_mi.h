@@ -157,6 +157,11 @@ int wm_op_layer_norm(float* out, const float* inp, const float* gamma, const flo
 int wm_op_mlp_block(float* x, const float* ln_g, const float* ln_b, const float* fc1_w, const float* fc1_b, const float* fc2_w,
                     const float* fc2_b, const float* next_g, const float* next_b, float* xn_out, int M, int d, int ffn, int dtype,
                     int gelu_mode);
+/* The block attention path of MultiHeadAttention.forward without cache and without mask (the encoder's: layers.mojo:273-342:
+ * per head gather, S = q_h·k_hᵀ, scale 1/8 after the product, row softmax, O = S·v_h, scatter).  q, k, v, out [n_ctx, 64·n_heads]
+ * fp32 host rows; dtype = operand rounding of q, k, v and of the probabilities (WM_F32: exact).  Runs the encoder's fused
+ * attention kernel (never materialises S).  Known-answer tests. */
+int wm_op_attention(float* out, const float* q, const float* k, const float* v, int n_ctx, int n_heads, int dtype);
 /* gelu(t) in place  whisper_tensor.mojo:288-308 (mode WM_GELU_TANH) */
 int wm_op_gelu(float* t, size_t n, int mode);
 /* softmax(t) rows in place  whisper_tensor.mojo:311-355 */

@@ -195,6 +195,70 @@ def test_op_mlp_block_fp32(hip):
     assert np.abs(xn - ref_xn).max() < 5e-5
 
 
+def _attention_ref(q, k, v, n_heads, rnd):
+    """layers.mojo:273-342 in float64 on the operands as the kernel sees them (rnd = operand rounding): per head
+    softmax(q_h·k_hᵀ · 0.125)·v_h — scale after the product (Q4), no mask."""
+    q, k, v = (rnd(a).astype(np.float64) for a in (q, k, v))
+    out = np.empty_like(q)
+    for h in range(n_heads):
+        sl = slice(64 * h, 64 * h + 64)
+        s_ = (q[:, sl] @ k[:, sl].T) * 0.125
+        s_ -= s_.max(axis=1, keepdims=True)
+        p = np.exp(s_)
+        out[:, sl] = (p / p.sum(axis=1, keepdims=True)) @ v[:, sl]
+    return out
+
+
+def _attention_case(name, n_ctx, n_heads, r):
+    d = 64 * n_heads
+    q, k, v = (r.standard_normal((n_ctx, d)).astype(np.float32) for _ in range(3))
+    if name == "growing":
+        # scores that keep outgrowing any earlier row maximum (and, for half the rows, keep falling): key j = u·(0.4 j), so
+        # s_ij = (q_i·u)·0.05 j reaches ±several hundred — the lazily refreshed softmax reference has to be refreshed many times
+        u = r.standard_normal(d).astype(np.float32)
+        u /= np.linalg.norm(u.reshape(n_heads, 64), axis=1).repeat(64)
+        k = (u[None, :] * (0.4 * np.arange(n_ctx, dtype=np.float32))[:, None]).astype(np.float32) + 0.1 * k
+    elif name == "outlier":
+        # one key in a middle tile beats everything by ~2^100, another row block sees it as hugely negative
+        j = n_ctx // 2 + 3
+        k[j] = 12.0 * np.sign(q[n_ctx // 3])
+    return q, k, v
+
+
+@pytest.mark.parametrize("case,n_ctx,n_heads", [("random", 1500, 6), ("growing", 1500, 6), ("outlier", 700, 8), ("random", 70, 6),
+                                                ("random", 64, 6), ("random", 1, 6), ("growing", 200, 2)])
+def test_op_attention_16bit(hip, case, n_ctx, n_heads):
+    """Encoder attention (fused, never writes S; softmax against a lazily refreshed reference maximum; key mask in a peeled last
+    tile) against float64 on the rounded operands: random scores, scores that keep growing / falling along the keys (the
+    reference maximum must be refreshed again and again), a 2^100 outlier in a middle tile, ragged and single-tile lengths."""
+    import torch
+    from whisper_mojo_amd import whisper_tensor as wt, DT_BF16, DT_F16
+    r = np.random.default_rng(n_ctx * 31 + n_heads)
+    q, k, v = _attention_case(case, n_ctx, n_heads, r)
+    for dt, rnd, tol in ((DT_BF16, _bf16_round, 8e-3), (DT_F16, lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).half().float().numpy(), 1e-3)):
+        ref = _attention_ref(q, k, v, n_heads, rnd)
+        out = wt.Tensor(n_ctx, 64 * n_heads)
+        wt.attention(out, q, k, v, n_heads, dtype=dt)
+        assert np.isfinite(out).all()
+        # probabilities and the output are rounded to 16 bits: ~2^-8 (bf16) / 2^-11 (f16) of the output's magnitude
+        # (measured, worst of the seven cases: 3.9e-3 bf16, 4.6e-4 f16 of max |out|)
+        assert np.abs(out - ref).max() < tol * max(1.0, np.abs(ref).max()), (case, dt, np.abs(out - ref).max())
+        again = wt.Tensor(n_ctx, 64 * n_heads)
+        wt.attention(again, q, k, v, n_heads, dtype=dt)
+        assert np.array_equal(out, again)
+
+
+def test_op_attention_fp32(hip):
+    from whisper_mojo_amd import whisper_tensor as wt, DT_F32
+    r = np.random.default_rng(5)
+    for case, n_ctx in (("random", 300), ("growing", 200)):
+        q, k, v = _attention_case(case, n_ctx, 6, r)
+        ref = _attention_ref(q, k, v, 6, lambda a: np.asarray(a, np.float32))
+        out = wt.Tensor(n_ctx, 384)
+        wt.attention(out, q, k, v, 6, dtype=DT_F32)
+        assert np.abs(out - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
 def test_op_layer_norm(hip, oracle_mod):
     from whisper_mojo_amd import whisper_tensor as wt
     for rows, cols in ((9, 384), (1, 128), (70, 512)):

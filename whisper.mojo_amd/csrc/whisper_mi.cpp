@@ -1972,6 +1972,7 @@ extern "C" int wm_op_layer_norm(float* out, const float* inp, const float* gamma
     return 0;
 }
 
+static void widen_to_f32(const void* src, int dtype, size_t n, float* dst);
 extern "C" int wm_op_mlp_block(float* x, const float* ln_g, const float* ln_b, const float* fc1_w, const float* fc1_b, const float* fc2_w,
                                const float* fc2_b, const float* next_g, const float* next_b, float* xn_out, int M, int d, int ffn,
                                int dtype, int gelu_mode) {
@@ -2042,23 +2043,52 @@ extern "C" int wm_op_mlp_block(float* x, const float* ln_g, const float* ln_b, c
     HIPCHK(hipMemcpy(x, dx.p, (size_t)M * d * 4, hipMemcpyDeviceToHost));
     if (want_next) {  // the operand rows as the next GEMM reads them, widened on the host
         const size_t n = (size_t)M * d;
-        if (dtype == WM_F32) {
-            HIPCHK(hipMemcpy(xn_out, xn.p, n * 4, hipMemcpyDeviceToHost));
+        std::vector<unsigned char> h(n * ts);
+        HIPCHK(hipMemcpy(h.data(), xn.p, h.size(), hipMemcpyDeviceToHost));
+        widen_to_f32(h.data(), dtype, n, xn_out);
+    }
+    return 0;
+}
+
+// widen n operand-dtype values on the host (known-answer entry points only)
+static void widen_to_f32(const void* src, int dtype, size_t n, float* dst) {
+    if (dtype == WM_F32) {
+        memcpy(dst, src, n * 4);
+        return;
+    }
+    const uint16_t* h = static_cast<const uint16_t*>(src);
+    for (size_t i = 0; i < n; ++i) {
+        if (dtype == WM_BF16) {
+            const uint32_t u = (uint32_t)h[i] << 16;
+            memcpy(&dst[i], &u, 4);
         } else {
-            std::vector<uint16_t> h(n);
-            HIPCHK(hipMemcpy(h.data(), xn.p, n * 2, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < n; ++i) {
-                if (dtype == WM_BF16) {
-                    const uint32_t u = (uint32_t)h[i] << 16;
-                    memcpy(&xn_out[i], &u, 4);
-                } else {
-                    _Float16 hv;
-                    memcpy(&hv, &h[i], 2);
-                    xn_out[i] = (float)hv;
-                }
-            }
+            _Float16 hv;
+            memcpy(&hv, &h[i], 2);
+            dst[i] = (float)hv;
         }
     }
+}
+
+extern "C" int wm_op_attention(float* out, const float* q, const float* k, const float* v, int n_ctx, int n_heads, int dtype) {
+    if (!out || !q || !k || !v || n_ctx <= 0 || n_heads <= 0 || n_heads > 64) return fail(WM_E_ARG, "bad argument");
+    if (dtype < 0 || dtype > 2) return fail(WM_E_ARG, "bad dtype");
+    const size_t d = (size_t)n_heads * 64, n = (size_t)n_ctx * d;
+    std::vector<float> packed(3 * n);  // the fused projection layout the kernel reads: row = [q | k | v]
+    for (int t = 0; t < n_ctx; ++t) {
+        memcpy(&packed[(size_t)t * 3 * d], q + (size_t)t * d, d * 4);
+        memcpy(&packed[(size_t)t * 3 * d + d], k + (size_t)t * d, d * 4);
+        memcpy(&packed[(size_t)t * 3 * d + 2 * d], v + (size_t)t * d, d * 4);
+    }
+    TmpDev t;
+    t.bufs.reserve(4);
+    DevBuf &qkv = t.add(), &o = t.add();
+    WMCHK(upload(qkv, packed.data(), packed.size(), dtype));
+    WMCHK(o.alloc(n * dt_size(dtype), true));
+    DISPATCH_DT(dtype, TT, launch_flash_attn_enc<TT>(qkv.p, o.p, 1, n_heads, n_ctx, 0.125f, nullptr));
+    HIPCHK(hipGetLastError());
+    std::vector<unsigned char> h(n * dt_size(dtype));
+    HIPCHK(hipMemcpy(h.data(), o.p, h.size(), hipMemcpyDeviceToHost));
+    widen_to_f32(h.data(), dtype, n, out);
     return 0;
 }
 

@@ -54,6 +54,17 @@ def mlp_block(x: np.ndarray, ln_g, ln_b, fc1_w, fc1_b, fc2_w, fc2_b, next_ln=Non
     return xn
 
 
+def attention(out: np.ndarray, q, k, v, n_heads: int, dtype=DT_F32):
+    """layers.mojo:273-342, the block path without cache or mask (the encoder's): per head softmax(q_h·k_hᵀ / 8)·v_h."""
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    q, k, v = f(q), f(k), f(v)
+    n_ctx, d = q.shape
+    if d != 64 * n_heads or k.shape != q.shape or v.shape != q.shape:
+        raise ValueError("q, k, v must be [n_ctx, 64 * n_heads]")
+    _chk_out(out, q.shape)
+    _lib.check(_lib.lib().wm_op_attention(_fp(out), _fp(q), _fp(k), _fp(v), n_ctx, n_heads, dtype))
+
+
 def layer_norm(out: np.ndarray, inp, gamma, beta, eps: float = 1e-5):
     """whisper_tensor.mojo:249-285"""
     x = np.ascontiguousarray(inp, np.float32)
