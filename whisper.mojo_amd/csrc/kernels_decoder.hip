@@ -104,12 +104,9 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
             for (int r = 0; r < 4; ++r) bias4[r] = p.bias[min(en + r, p.N - 1)];
         }
         if (p.residual) res4 = *reinterpret_cast<const f32x4*>(p.residual + (size_t)eb * p.ldr + en);
-        // (a VECTOR load: the scalar form would put another scalar round trip — kernarg -> ctl -> len — in front of the weight loads)
-#ifdef WM_SCALAR_LEN  // developer A/B
-        if (p.kcache) cache_row = p.ctl->len;
-#else
+        // (the address is uniform, so hipcc emits a scalar load whatever the source says — kernarg -> ctl -> len is one more
+        //  scalar round trip in the prologue; in-kernel stamps showed the prologue's scalar stages are not what delays the loads)
         if (p.kcache) cache_row = __builtin_nontemporal_load(&p.ctl->len);
-#endif
     }
     Frag<TW> wf[NT][KPW];
     Frag<TW> xft[XT ? KPW : 1];

@@ -1092,7 +1092,7 @@ __device__ __forceinline__ f16x4 lds_tr16(const f16* p) {
     return __builtin_bit_cast(f16x4, v);
 }
 
-template <typename T, int NW, int QB, int WPS = 1, int OPT = 0>
+template <typename T, int NW, int QB, int WPS = 1, int OPT = 0 /* 1: exact running maximum on every tile (developer A/B) */>
 __global__ __launch_bounds__(NW * 64, WPS) void flash_attn_enc_v2_kernel(const T* __restrict__ qkv, T* __restrict__ out, int n_ctx,
                                                                     int d_model, float scale_log2e, int xcd_remap) {
     // 160-byte rows (40 dwords): with the hardware's lane groups (ds_read_b128: {0-3,12-15,20-27}, ...; ds_read_b64_tr:
