@@ -56,3 +56,24 @@ def test_package_import_sets_hw_queue_default():
     import os
     import whisper_mojo_amd  # noqa: F401
     assert int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) >= 8
+
+
+def test_op_wrappers_validate_shapes_before_calling_the_library():
+    """The host mirrors of the op entry points refuse wrong shapes themselves (no GPU, no library call needed to see it)."""
+    import numpy as np
+    import pytest
+    from whisper_mojo_amd import whisper_tensor as wt
+    x = np.zeros((4, 128), np.float32)
+    with pytest.raises(ValueError):  # fc1 must be [ffn, d]
+        wt.mlp_block(x, np.ones(128), np.zeros(128), np.zeros((256, 64), np.float32), np.zeros(256), np.zeros((128, 256), np.float32), np.zeros(128))
+    with pytest.raises(ValueError):  # fc2 must be [d, ffn]
+        wt.mlp_block(x, np.ones(128), np.zeros(128), np.zeros((256, 128), np.float32), np.zeros(256), np.zeros((128, 128), np.float32), np.zeros(128))
+    with pytest.raises(ValueError):  # in place: x must be a C-contiguous float32 array
+        wt.mlp_block(x.astype(np.float64), np.ones(128), np.zeros(128), np.zeros((256, 128), np.float32), np.zeros(256), np.zeros((128, 256), np.float32), np.zeros(128))
+    q = np.zeros((10, 128), np.float32)
+    with pytest.raises(ValueError):  # d must be 64 * n_heads
+        wt.attention(np.zeros_like(q), q, q, q, 3)
+    with pytest.raises(ValueError):  # k of another length
+        wt.attention(np.zeros_like(q), q, np.zeros((9, 128), np.float32), q, 2)
+    with pytest.raises(ValueError):  # out of the wrong shape
+        wt.attention(np.zeros((10, 64), np.float32), q, q, q, 2)
