@@ -13,7 +13,7 @@ m = Whisper(cfg, compute_dtype=DT_BF16, max_batch=B); m.load(WeightLoader.from_a
 st = C.c_void_p(); _lib.check(L.wm_state_new(m._h, B, C.byref(st)))
 _lib.check(L.wm_encode(m._h, st, mel.ctypes.data_as(C.c_void_p), 0, B, None))
 us = C.c_float()
-for which in (40, 41, 42):
+for which in ((40, 41, 42, 43) if len(sys.argv) < 2 else [int(a) for a in sys.argv[1:]]):
     for _ in range(3):
         _lib.check(L.wm_bench_kernel(m._h, st, which, 1, C.byref(us)))
         print("event us", us.value)

@@ -294,21 +294,30 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_nt_rowpanel_kernel(GemmParams
             s_gb[KS * 32 + i] = p.ln_b[i];
         }
     }
+#ifdef WM_DEV
+    // developer: 100 MHz wall-clock stamps of wave 0, first three units, kept in LDS (a global store would enter the counted VMEM
+    // queue) and dumped at the end: per stage [top, past the barrier, DMAs issued, MFMAs issued], per unit [epilogue start, end]
+    long long* s_dbg = reinterpret_cast<long long*>(s_gb + (LNA ? 2 * KS * 32 : 0));
+    const bool dbg_on = p.dbg != nullptr && w == 0 && lane == 0;
+#define WM_RP_STAMP(UU, K) do { if (dbg_on && (UU) < 3) s_dbg[(UU) * 32 + (K)] = (long long)wall_clock64(); } while (0)
+#else
+#define WM_RP_STAMP(UU, K) do { } while (0)
+#endif
     __syncthreads();  // before any DMA is in flight: a __syncthreads() later would drain the ring (vmcnt(0))
 
-    auto issue = [&](int s) {  // stage s of this workgroup's stream -> ring slot s % 4
+    // DMA source = (uniform base of the stage's piece) + (this lane's 32-bit byte offset, the same for every stage and piece): as
+    // stage_tile, piece i = W rows 8i .. 8i+7 of the column tile, 16-byte chunk c of row r at position c ^ (r & 7) — and
+    // (8 i + lane / 8) & 7 == lane / 8 whatever i.  No per-issue address arithmetic in vector registers.
+    const unsigned woff = (unsigned)((((size_t)(8 * w * PPW + (lane >> 3))) * p.ldw + (((lane & 7) ^ (lane >> 3)) << 3)) * sizeof(T));
+    auto issue = [&](int s) {  // stage s of this workgroup's stream -> ring slot s % NSLOT
         const int u = u0 + s / SPU, t = s % SPU;
         const int ct = u % nct;
-        const T* gbase = Wg + (size_t)ct * 128 * p.ldw + t * 64;
-        T* slot = ring + (s & (NSLOT - 1)) * SLOT;
+        const char* gbase = reinterpret_cast<const char*>(Wg + (size_t)ct * 128 * p.ldw + t * 64);
+        T* slot = ring + (s & (NSLOT - 1)) * SLOT + w * PPW * 512;
 #pragma unroll
-        for (int j = 0; j < PPW; ++j) {  // as stage_tile: piece i = rows 8i .. 8i+7, 16-byte chunk c of row r at position c ^ (r & 7)
-            const int i = w * PPW + j;
-            const int row = 8 * i + (lane >> 3), cp = lane & 7;
-            const T* g = gbase + (size_t)row * p.ldw + ((cp ^ (row & 7)) << 3);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(slot + i * 512), 16, 0, 0);
-        }
+        for (int j = 0; j < PPW; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + (size_t)j * 8 * p.ldw * sizeof(T) + woff),
+                                             (__attribute__((address_space(3))) void*)(slot + j * 512), 16, 0, 0);
     };
 #pragma unroll
     for (int s = 0; s < AHEAD; ++s)
@@ -393,6 +402,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_nt_rowpanel_kernel(GemmParams
             // Younger than stage s are min(AHEAD - 1, rem) stages of PPW DMAs each — 8 in the steady state for either shape —
             // plus, while the unit's first AHEAD stages are multiplied, the previous epilogue's stores.
             const int rem = n_stage - 1 - s;
+            WM_RP_STAMP(u - u0, t * 4 + 0);
             if (t == 0 && newp) {  // fresh A fragments: the compiler waits vmcnt(0) for them anyway
                 WM_RP_WAIT(0);
             } else if (rem >= AHEAD - 1) {
@@ -433,7 +443,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_nt_rowpanel_kernel(GemmParams
                 else
                     WM_RP_WAIT(0);
             }
+            WM_RP_STAMP(u - u0, t * 4 + 1);
             if (s + AHEAD < n_stage) issue(s + AHEAD);
+            WM_RP_STAMP(u - u0, t * 4 + 2);
             const T* Ws = ring + (s & (NSLOT - 1)) * SLOT;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -453,7 +465,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_nt_rowpanel_kernel(GemmParams
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // 16 MFMAs
             }
+            WM_RP_STAMP(u - u0, t * 4 + 3);
         }
+        WM_RP_STAMP(u - u0, 24);
         // epilogue: acc[j][i][r] = C[pn*128 + w*32 + 16i + r16][ct*128 + 16j + 4g + r]
         TO* Cb = (TO*)p.C;
         int ncol = ct * 128;
@@ -516,14 +530,24 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_nt_rowpanel_kernel(GemmParams
             st_pend = __builtin_amdgcn_readfirstlane((int)(pn * PR + w * 32 + 32 <= p.M)) != 0;
         }
         if (!st_pend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WM_RP_STAMP(u - u0, 25);
     }
 #undef WM_RP_WAIT
+#ifdef WM_DEV
+    if (dbg_on) {
+        for (int i = 0; i < 96; ++i) p.dbg[(size_t)blockIdx.x * 96 + i] = s_dbg[i];
+    }
+#endif
+#undef WM_RP_STAMP
 }
 template <typename T, typename TO, int KS, bool LNA, int NW> static void launch_rowpanel_t(const GemmParams& p, hipStream_t st) {
     const int n_units = ((p.M + NW * 32 - 1) / (NW * 32)) * (p.N / 128);
     static const int grid_env = wm_env("WM_RP_GRID") ? atoi(wm_env("WM_RP_GRID")) : 0;
     const int grid = std::min(n_units, grid_env > 0 ? grid_env : (NW == 4 ? 512 : 256));  // two 64-KB-ring workgroups per CU, or one of 128 KB
-    const size_t lds = (size_t)(NW == 4 ? 4 : 8) * 128 * 64 * sizeof(T) + (size_t)p.N * 4 + (LNA ? (size_t)2 * KS * 32 * 4 : 0);
+    size_t lds = (size_t)(NW == 4 ? 4 : 8) * 128 * 64 * sizeof(T) + (size_t)p.N * 4 + (LNA ? (size_t)2 * KS * 32 * 4 : 0);
+#ifdef WM_DEV
+    lds += 96 * 8;  // phase stamps
+#endif
     (void)ensure_dyn_lds(&gemm_nt_rowpanel_kernel<T, TO, KS, LNA, NW>, NW == 4 ? 80 * 1024 : 144 * 1024);  // per device; a failure surfaces through hipGetLastError
     hipLaunchKernelGGL((gemm_nt_rowpanel_kernel<T, TO, KS, LNA, NW>), dim3(grid), dim3(NW * 64), lds, st, p, n_units);
 }

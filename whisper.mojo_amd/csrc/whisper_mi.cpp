@@ -1824,6 +1824,47 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
         fprintf(stderr, "[wm] dec_linear %s phases (us after the first wave's entry; mean / max over %d waves): entry %.2f/%.2f  loads issued %.2f/%.2f  operands ready %.2f/%.2f  MFMA + partial stored %.2f/%.2f  after barrier %.2f/%.2f  end %.2f/%.2f\n",
                 which == 41 ? "LN1+QKV" : "O-proj", n, av[0] / n, mx[0], av[1] / n, mx[1], av[2] / n, mx[2], av[3] / n, mx[3], av[4] / n, mx[4], av[5] / n, mx[5]);
         dbg.release();
+    } else if (which == 43) {  // developer: phase stamps of the encoder's QKV row-panel GEMM (layer 0) on the rows of the last encode
+        const wm_dims& c = m->cfg.dims;
+        const int T = m->cfg.compute_dtype;
+        const int M = std::min(s->B, s->Bc) * c.n_audio_ctx;
+        EncLayer& w0 = m->enc[0];
+        GemmParams p{};
+        p.A = s->xn.p; p.W = w0.qkv_w.p; p.C = s->qkv.p; p.M = M; p.N = 3 * c.d_model; p.K = c.d_model;
+        p.lda = c.d_model; p.ldw = c.d_model; p.ldc = 3 * c.d_model; p.bias = w0.qkv_b.as<float>();
+        if (!gemm_nt_fuses_layernorm(T == WM_F32 ? 4 : 2, p, 1)) return fail(WM_E_ARG, "this configuration does not run the row-panel kernel");
+        for (int i = 0; i < 3; ++i) gemm_dispatch(T, T, p, 1, st);
+        DevBuf dbg;
+        WMCHK(dbg.alloc((size_t)512 * 96 * 8, true));
+        p.dbg = dbg.as<long long>();
+        HIPCHK(hipEventRecord(e0, st));
+        gemm_dispatch(T, T, p, 1, st);
+        HIPCHK(hipEventRecord(e1, st));
+        HIPCHK(hipEventSynchronize(e1));
+        std::vector<long long> h((size_t)512 * 96);
+        HIPCHK(hipMemcpy(h.data(), dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
+        double wait = 0, issue = 0, comp = 0, epi = 0, gap = 0, unit = 0;
+        int ns = 0, nu = 0, ng = 0;
+        for (int g = 0; g < 512; ++g)
+            for (int uu = 1; uu < 3; ++uu) {  // second and third unit of each workgroup (the first carries the panel load)
+                const long long* d = &h[(size_t)g * 96 + uu * 32];
+                if (d[0] <= 0 || d[25] <= 0) continue;
+                for (int t = 0; t < 6; ++t) {
+                    wait += (double)(d[t * 4 + 1] - d[t * 4 + 0]);
+                    issue += (double)(d[t * 4 + 2] - d[t * 4 + 1]);
+                    comp += (double)(d[t * 4 + 3] - d[t * 4 + 2]);
+                    if (t > 0) { gap += (double)(d[t * 4] - d[t * 4 - 1]); ++ng; }
+                    ++ns;
+                }
+                epi += (double)(d[25] - d[24]);
+                unit += (double)(d[25] - d[0]);
+                ++nu;
+            }
+        if (ns)
+            fprintf(stderr, "[wm] row-panel QKV, wave 0, per 64-k stage (ns): wait + barrier %.0f  DMA issue %.0f  fragment reads + 32 MFMAs issued %.0f  to next top %.0f | "
+                            "per unit: epilogue %.0f, whole unit %.0f (%d stages, %d units)\n",
+                    wait / ns * 10, issue / ns * 10, comp / ns * 10, ng ? gap / ng * 10 : 0.0, epi / nu * 10, unit / nu * 10, ns, nu);
+        dbg.release();
     } else if (which == 40) {  // developer: phase stamps of one logits launch (after a few warm ones), printed to stderr
         const wm_dims& c = m->cfg.dims;
         const int T = dec_dtype(m->cfg);

@@ -63,6 +63,7 @@ struct GemmParams {
     const float* lno_g;
     const float* lno_b;
     void* lno_out;
+    long long* dbg;  // developer build: phase stamps of the row-panel kernel (wm_bench_kernel id 43), else null
 };
 bool gemm_nt_fuses_layernorm_out(int operand_bytes, const GemmParams& p);
 // true when launch_gemm_nt<T, *> takes the A-stationary row-panel kernel for these parameters (the only one that can fuse a LayerNorm)
