@@ -591,7 +591,7 @@ bool gemm_nt_fuses_layernorm(int operand_bytes, const GemmParams& p, int batch) 
 //   step X(t): barrier; refill; request the 8 fragments of Y(t); wait until X(t)'s 12 are in; 16 MFMAs
 //   step Y(t): barrier; refill; request the 12 fragments of X(t+1); wait until Y(t)'s 8 are in; 32 MFMAs (A fragments of X(t) kept)
 // At every barrier each wave holds the previous half-stage in registers, so the slot before it is free for the refill.
-template <typename T, bool LNO>
+template <typename T, bool LNO, bool ACT>
 __global__ __launch_bounds__(512) void gemm_nt_fullrow_kernel(GemmParams p) {
     constexpr int NSLOT = 4, SLOT = 256 * 64;  // elements per ring slot (32 KB)
     extern __shared__ __attribute__((aligned(16))) unsigned char fr_smem[];
@@ -746,38 +746,46 @@ __global__ __launch_bounds__(512) void gemm_nt_fullrow_kernel(GemmParams p) {
 #undef WM_FR_TOP
 #undef WM_FR_HOLD_X
 #undef WM_FR_HOLD_Y
-    // epilogue: acc[j][i][r] = C[m0 + 64 wr + 16 i + r16][colj(j) + 4 g + r];  out = act(acc + bias) + pos + residual
+    // epilogue: acc[j][i][r] = C[m0 + 64 wr + 16 i + r16][colj(j) + 4 g + r];  out = act(acc + bias) + pos + residual.
+    // Every addend row of all four row blocks is requested before anything is stored (the fragment registers are free now: 96
+    // more live values fit): written row block by row block, each block's loads waited for the previous block's STORES too
+    // (loads and stores share the in-order vmcnt) — four exposed memory round trips per workgroup, at one workgroup per CU.
     float* Cb = (float*)p.C + (size_t)bz * p.strideC;
     float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x4 bv[6];
+    f32x4 bv[6], ex[4][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) bv[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + colj(j) + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    int mrow[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wr * 64 + i * 16 + r16;
-        const bool valid = m < p.M;
-        const int ml = valid ? m : p.M - 1;
-        f32x4 ex[6];
+        mrow[i] = m < p.M ? m : p.M - 1;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) ex[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.residual) {
-            const float* rr = p.residual + (size_t)bz * p.strideR + (size_t)ml * p.ldr + g * 4;
+        for (int j = 0; j < 6; ++j) ex[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float* addend = p.residual ? p.residual + (size_t)bz * p.strideR + g * 4 : p.pos ? p.pos + g * 4 : nullptr;
+    const long ld_add = p.residual ? p.ldr : p.N;
+    if (addend) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) ex[j] = *reinterpret_cast<const f32x4*>(rr + colj(j));
-        }
-        if (p.pos) {
-            const float* pr = p.pos + (size_t)ml * p.N + g * 4;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) ex[j] += *reinterpret_cast<const f32x4*>(pr + colj(j));
-        }
-        float* crow = Cb + (size_t)ml * p.ldc + g * 4;
+            for (int j = 0; j < 6; ++j) ex[i][j] = *reinterpret_cast<const f32x4*>(addend + (size_t)mrow[i] * ld_add + colj(j));
+    }
+    if (p.residual && p.pos) {  // both (no caller today): the positional rows in a second round
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) ex[i][j] += *reinterpret_cast<const f32x4*>(p.pos + g * 4 + (size_t)mrow[i] * p.N + colj(j));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool valid = m0 + wr * 64 + i * 16 + r16 < p.M;
+        float* crow = Cb + (size_t)mrow[i] * p.ldc + g * 4;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             f32x4 v = acc[j][i] + bv[j];
-            if (p.act) {
-                v = gelu_fast4(v, p.gelu_mode);
-            }
-            v += ex[j];
+            if constexpr (ACT) v = gelu_fast4(v, p.gelu_mode);
+            v += ex[i][j];
             if (valid) *reinterpret_cast<f32x4*>(crow + colj(j)) = v;
             if constexpr (LNO) {
                 acc[j][i] = v;
@@ -858,16 +866,19 @@ bool gemm_nt_fuses_layernorm_out(int operand_bytes, const GemmParams& p) {
     static const bool off = wm_env("WM_GEMM_NO_LN_OUT") != nullptr;
     return !off && fullrow_ok(operand_bytes, p);
 }
-template <typename T> static void launch_fullrow(const GemmParams& p, int batch, hipStream_t st) {
+template <typename T, bool LNO, bool ACT> static void launch_fullrow_t(const GemmParams& p, int batch, hipStream_t st) {
     const int lds = 4 * 256 * 64 * (int)sizeof(T);  // 128 KB: one workgroup per CU
     dim3 grid((p.M + 127) / 128, batch);
+    (void)ensure_dyn_lds(&gemm_nt_fullrow_kernel<T, LNO, ACT>, lds);  // per device; a failure surfaces through hipGetLastError
+    hipLaunchKernelGGL((gemm_nt_fullrow_kernel<T, LNO, ACT>), grid, dim3(512), lds, st, p);
+}
+template <typename T> static void launch_fullrow(const GemmParams& p, int batch, hipStream_t st) {
     if (p.lno_out) {
-        (void)ensure_dyn_lds(&gemm_nt_fullrow_kernel<T, true>, lds);  // per device; a failure surfaces through hipGetLastError
-        hipLaunchKernelGGL((gemm_nt_fullrow_kernel<T, true>), grid, dim3(512), lds, st, p);
-    } else {
-        (void)ensure_dyn_lds(&gemm_nt_fullrow_kernel<T, false>, lds);
-        hipLaunchKernelGGL((gemm_nt_fullrow_kernel<T, false>), grid, dim3(512), lds, st, p);
+        if (p.act) return launch_fullrow_t<T, true, true>(p, batch, st);
+        return launch_fullrow_t<T, true, false>(p, batch, st);
     }
+    if (p.act) return launch_fullrow_t<T, false, true>(p, batch, st);
+    launch_fullrow_t<T, false, false>(p, batch, st);
 }
 
 template <typename T, typename TO> void launch_gemm_nt(const GemmParams& p, int batch, hipStream_t st) {
