@@ -149,6 +149,14 @@ int wm_op_matmul_nt(float* C, const float* A, const float* B, const float* bias,
 /* layer_norm(out, inp, gamma, beta, eps)  whisper_tensor.mojo:249-285 (one-pass variance). cols % 128 == 0, <= 1024 */
 int wm_op_layer_norm(float* out, const float* inp, const float* gamma, const float* beta, int rows, int cols,
                      float eps);
+/* The q_len == 1 path of MultiHeadAttention.forward over cached keys / values (layers.mojo:186-272): per utterance and head
+ * s_j = (q·K_j)·0.125 (scale AFTER the dot product), running max from -1e10, p = exp(s - max), o = Σ p_j V_j / Σ p_j.
+ * q, out [B, 64·n_heads] fp32; k, v [B, t, 64·n_heads] fp32 host rows, rounded to kv_dtype as the cache holds them.
+ * n_chunks > 1: the keys of an utterance are swept by n_chunks workgroups and merged (the cross-attention form; needs
+ * t/512 <= n_chunks <= t/32 rounded up);  n_chunks == 1: one workgroup per utterance, the key count read from the decode
+ * control block (the self-attention form).  Known-answer tests. */
+int wm_op_attention_cached(float* out, const float* q, const float* k, const float* v, int B, int t, int n_heads, int kv_dtype,
+                           int n_chunks);
 /* The MLP half of ResidualAttentionBlock.forward  layers.mojo:489-517 :  x += fc2(gelu(fc1(layer_norm(x, ln_g, ln_b)))),
  * x [M, d] in place; fc1_w [ffn, d], fc2_w [d, ffn] (HF [out, in]).  With next_g / next_b / xn_out non-NULL also returns
  * layer_norm(x_new, next_g, next_b) rounded to the operand dtype (what the next projection is fed) in xn_out [M, d].

@@ -77,3 +77,7 @@ def test_op_wrappers_validate_shapes_before_calling_the_library():
         wt.attention(np.zeros_like(q), q, np.zeros((9, 128), np.float32), q, 2)
     with pytest.raises(ValueError):  # out of the wrong shape
         wt.attention(np.zeros((10, 64), np.float32), q, q, q, 2)
+    with pytest.raises(ValueError):  # cached keys must be [B, t, d]
+        wt.attention_cached(np.zeros_like(q), q, q, q, 2)
+    with pytest.raises(ValueError):  # another batch size in the cache
+        wt.attention_cached(np.zeros_like(q), q, np.zeros((9, 5, 128), np.float32), np.zeros((9, 5, 128), np.float32), 2)

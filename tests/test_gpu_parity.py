@@ -259,6 +259,42 @@ def test_op_attention_fp32(hip):
         assert np.abs(out - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
 
 
+def _attention_cached_ref(q, k, v, n_heads, rnd):
+    """layers.mojo:186-272 in float64: per utterance and head s_j = (q·K_j)·0.125, softmax over the cached rows, o = Σ p_j V_j."""
+    q = q.astype(np.float64)
+    k, v = rnd(k).astype(np.float64), rnd(v).astype(np.float64)
+    out = np.empty_like(q)
+    for h in range(n_heads):
+        sl = slice(64 * h, 64 * h + 64)
+        s_ = np.einsum("bd,btd->bt", q[:, sl], k[:, :, sl]) * 0.125
+        s_ -= s_.max(axis=1, keepdims=True)
+        p = np.exp(s_)
+        out[:, sl] = np.einsum("bt,btd->bd", p / p.sum(axis=1, keepdims=True), v[:, :, sl])
+    return out
+
+
+@pytest.mark.parametrize("B,t,chunks", [(1, 1, 1), (3, 7, 1), (5, 200, 1), (2, 448, 1), (1, 1500, 16), (5, 1500, 16), (3, 1500, 47), (2, 97, 3)])
+def test_op_attention_cached(hip, B, t, chunks):
+    """The decode attention (q_len == 1 over cached K/V: the single-workgroup self-attention form and the chunked + merged
+    cross-attention form) against float64 on the cache as stored, for fp32 / bf16 / f16 caches; queries stay fp32."""
+    import torch
+    from whisper_mojo_amd import whisper_tensor as wt, DT_F32, DT_BF16, DT_F16
+    r = np.random.default_rng(B * 1000 + t)
+    H = 6
+    q = (r.standard_normal((B, 64 * H)) * 1.5).astype(np.float32)
+    k = r.standard_normal((B, t, 64 * H)).astype(np.float32)
+    v = r.standard_normal((B, t, 64 * H)).astype(np.float32)
+    if t > 4:
+        k[:, t // 2] = 3.0 * np.sign(q)  # one dominant key: the running-max path matters
+    h16 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).half().float().numpy()
+    for dt, rnd, tol in ((DT_F32, lambda a: a, 2e-5), (DT_BF16, _bf16_round, 2e-5), (DT_F16, h16, 2e-5)):
+        ref = _attention_cached_ref(q, k, v, H, rnd)
+        out = wt.Tensor(B, 64 * H)
+        wt.attention_cached(out, q, k, v, H, kv_dtype=dt, n_chunks=chunks)
+        # the cache rounding is in the reference; what is left is fp32 arithmetic
+        assert np.abs(out - ref).max() < tol * max(1.0, np.abs(ref).max()), (dt, np.abs(out - ref).max())
+
+
 def test_op_layer_norm(hip, oracle_mod):
     from whisper_mojo_amd import whisper_tensor as wt
     for rows, cols in ((9, 384), (1, 128), (70, 512)):

@@ -2133,6 +2133,56 @@ extern "C" int wm_op_attention(float* out, const float* q, const float* k, const
     return 0;
 }
 
+extern "C" int wm_op_attention_cached(float* out, const float* q, const float* k, const float* v, int B, int t, int n_heads, int kv_dtype,
+                                      int n_chunks) {
+    if (!out || !q || !k || !v || B <= 0 || t <= 0 || n_heads <= 0 || n_heads > 16) return fail(WM_E_ARG, "bad argument");
+    if (kv_dtype < 0 || kv_dtype > 2) return fail(WM_E_ARG, "bad dtype");
+    if (n_chunks < 1 || (n_chunks > 1 && (n_chunks < (t + 511) / 512 || n_chunks > (t + 31) / 32)))
+        return fail(WM_E_ARG, "n_chunks must be 1, or between ceil(t/512) and ceil(t/32)");
+    if (n_chunks == 1 && t > 512) return fail(WM_E_ARG, "the single-workgroup form serves up to 512 keys (the text context)");
+    const size_t d = (size_t)n_heads * 64;
+    TmpDev tmp;
+    tmp.bufs.reserve(8);
+    DevBuf &dq = tmp.add(), &dk = tmp.add(), &dv = tmp.add(), &po = tmp.add(), &pml = tmp.add(), &o = tmp.add(), &ctl = tmp.add();
+    WMCHK(upload(dq, q, (size_t)B * d, WM_F32));
+    WMCHK(upload(dk, k, (size_t)B * t * d, kv_dtype));
+    WMCHK(upload(dv, v, (size_t)B * t * d, kv_dtype));
+    WMCHK(o.alloc((size_t)B * d * 4, true));
+    AttnDecParams a{};
+    a.q = dq.as<float>();
+    a.K = dk.p;
+    a.V = dv.p;
+    a.batch_stride = (long)((size_t)t * d);
+    a.scale = 0.125f;
+    a.H = n_heads;
+    a.d = (int)d;
+    a.B = B;
+    if (n_chunks > 1) {
+        WMCHK(po.alloc((size_t)B * n_chunks * d * 4, true));
+        WMCHK(pml.alloc((size_t)B * n_chunks * n_heads * 2 * 4, true));
+        a.n_keys = t;
+        a.nsplit = n_chunks;
+        a.part_o = po.as<float>();
+        a.part_ml = pml.as<float>();
+        attn_decode_dispatch(kv_dtype, a, nullptr);
+        launch_attn_combine(po.as<float>(), pml.as<float>(), o.p, WM_F32, B, n_chunks, n_heads, (int)d, nullptr);
+    } else {
+        StepCtl h{};
+        h.len = t - 1;  // the kernel sweeps len + 1 rows: the cache as it stands after this step's row was appended
+        WMCHK(ctl.alloc(sizeof(StepCtl)));
+        HIPCHK(hipMemcpy(ctl.p, &h, sizeof h, hipMemcpyHostToDevice));
+        a.n_keys = -1;
+        a.ctl = ctl.as<StepCtl>();
+        a.nsplit = 1;
+        a.direct_out = o.as<float>();
+        a.out_dtype = WM_F32;
+        attn_decode_dispatch(kv_dtype, a, nullptr);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, o.p, (size_t)B * d * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int wm_op_gelu(float* tt, size_t n, int mode) {
     if (!tt || (mode != 0 && mode != 1)) return fail(WM_E_ARG, "bad argument");
     if (n == 0) return 0;

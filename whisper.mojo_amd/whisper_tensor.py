@@ -65,6 +65,18 @@ def attention(out: np.ndarray, q, k, v, n_heads: int, dtype=DT_F32):
     _lib.check(_lib.lib().wm_op_attention(_fp(out), _fp(q), _fp(k), _fp(v), n_ctx, n_heads, dtype))
 
 
+def attention_cached(out: np.ndarray, q, k, v, n_heads: int, kv_dtype=DT_F32, n_chunks: int = 1):
+    """layers.mojo:186-272, the q_len == 1 path over cached rows: q [B, d], k / v [B, t, d] -> out [B, d].
+    n_chunks > 1: the cross-attention form (keys swept by several workgroups and merged)."""
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    q, k, v = f(q), f(k), f(v)
+    B, d = q.shape
+    if d != 64 * n_heads or k.ndim != 3 or k.shape[0] != B or k.shape[2] != d or v.shape != k.shape:
+        raise ValueError("q must be [B, 64 * n_heads], k and v [B, t, 64 * n_heads]")
+    _chk_out(out, q.shape)
+    _lib.check(_lib.lib().wm_op_attention_cached(_fp(out), _fp(q), _fp(k), _fp(v), B, k.shape[1], n_heads, kv_dtype, n_chunks))
+
+
 def layer_norm(out: np.ndarray, inp, gamma, beta, eps: float = 1e-5):
     """whisper_tensor.mojo:249-285"""
     x = np.ascontiguousarray(inp, np.float32)
