@@ -337,6 +337,22 @@ def test_op_conv1d(hip, oracle_mod, C_in, L, stride, out_T):
     assert np.abs(out - ref).max() < 2e-5
 
 
+@pytest.mark.parametrize("C_in,L,stride", [(384, 3000, 2), (384, 601, 2), (384, 257, 1)])
+def test_op_conv1d_bf16_full_row(hip, oracle_mod, C_in, L, stride):
+    """conv2's shape (C_out = 384, K = 3·384) with 16-bit operands: the implicit GEMM over overlapping input rows runs on the
+    full-row kernel (ragged last panel, lda = stride·C_in).  Against the oracle on the rounded operands (fp32 accumulate)."""
+    from whisper_mojo_amd import whisper_tensor as wt, DT_BF16
+    r = np.random.default_rng(C_in + L)
+    x = r.standard_normal((C_in, L)).astype(np.float32)
+    w = (r.standard_normal((384, C_in, 3)) / np.sqrt(3 * C_in)).astype(np.float32)
+    b = r.standard_normal(384).astype(np.float32)
+    L_out = (L + 2 - 3) // stride + 1
+    out = wt.Tensor(L_out, 384)
+    wt.conv1d(out, x, w, b, stride, 1, True, dtype=DT_BF16)
+    ref = oracle_mod.conv1d(_bf16_round(x), oracle_mod.transpose_conv_weights(_bf16_round(w)), b, stride, 1, True)
+    assert np.abs(out - ref).max() < 2e-4, np.abs(out - ref).max()
+
+
 # ---------------------------------------------------------------------------------------------- model-level
 def _first_divergence(got, want):
     n = min(len(got), len(want))
