@@ -6,8 +6,11 @@ One "step" = one full transcribe pass (encoder + prompt prefill + 99 greedy deco
 SURVEY §8d, + the RCCL all-gather of token buffers when N>1) over one batch of synthetic 80x3000 mels that are
 already resident in HBM.  Rank 0 prints ONE JSON line.
 
-    python bench.py                                   # N=1, tiny, B=64, bf16 operands (BASELINE config 3)
+    python bench.py                                   # N=1: BASELINE config 3 as written — tiny, B=64, bf16 encoder GEMMs; decoder weights,
+                                                      # operands and KV cache fp32 (workload tiny_b64_bf16enc_f32dec)
+    python bench.py --workload tiny_b64_bf16          # the all-16-bit variant (bf16 operands in the decoder too, bf16 KV)
     python bench.py --workload tiny_b1_f32            # BASELINE config 2
+    python bench.py --workload base_b64_f16           # BASELINE config 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W        # BASELINE config 4 at N=8
 
@@ -16,8 +19,9 @@ Besides the contract's keys the line carries (all timed in this same run, N = 1 
                      (SURVEY §8d's literal timed region; `value` keeps the mels resident, as the bench contract asks)
   unpipelined        the K steps strictly one after another
   natural            the reference's stop rule (eot 50257, <= 195 iterations, whisper.mojo:205-206) instead of the fixed 99
-  precision_ladder   the other precisions of the same model, a few steps each: bf16 operands + fp32 KV, everything fp32
-                     (the reference's own precision) at B = 64, and BASELINE config 2 (B = 1, fp32)
+  value_all_16bit    the same passes with bf16 operands in the decoder too and a bf16 KV cache (round 2's headline; narrower than config 3)
+  precision_ladder   the other precisions / configurations, a few steps each: all-16-bit, bf16 operands + fp32 KV, everything fp32
+                     (the reference's own precision) at B = 64, BASELINE config 2 (B = 1, fp32) and config 5 (base, B = 64, f16)
   roofline / decode_step / decode_step_4_in_flight / encoder / cpu_baseline   as in round 1
 """
 import argparse
@@ -46,11 +50,24 @@ WORKLOADS = {
     "tiny_b64_bf16enc_f32dec": ("tiny", 64, "bf16", "f32"),
 }
 DECODER_FP32 = {"tiny_b64_bf16enc_f32dec"}
-LADDER = ["tiny_b64_bf16enc_f32dec", "tiny_b64_bf16_kv32", "tiny_b64_f32", "tiny_b1_f32", "tiny_b128_bf16"]
+DEFAULT_WORKLOAD = "tiny_b64_bf16enc_f32dec"  # BASELINE config 3 as written
+LADDER = ["tiny_b64_bf16enc_f32dec", "tiny_b64_bf16", "base_b64_f16", "tiny_b64_bf16_kv32", "tiny_b64_f32", "tiny_b1_f32", "tiny_b128_bf16"]
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 DECODE_STEPS = 99      # + 1 token from the prefill = 100 generated ids per utterance
 NATURAL_LOOP = 195     # whisper.mojo:205
 CLIP_SECONDS = 30.0
+
+
+def precision_of(workload, cdt, kdt):
+    """(dtype field, sentence) — what is narrowed below the reference's fp32 and what is not."""
+    if workload in DECODER_FP32:
+        return (f"{cdt} encoder GEMMs; f32 decoder + KV",
+                f"GEMM operands {cdt} in the ENCODER only (conv stem, encoder blocks, cross-K/V projection: weights and the activations fed to "
+                f"MFMA); the decoder's weights and MFMA operands and the self-/cross-attention KV cache are fp32 — BASELINE config 3 as written")
+    if cdt == "f32":
+        return ("f32", "everything fp32 (exact-fp32 MFMA), the reference's precision")
+    return (f"{cdt} operands, {kdt} KV",
+            f"GEMM operands {cdt} in the encoder AND the decoder (weights, activations fed to MFMA), KV cache {kdt}")
 
 
 def log(msg):
@@ -93,9 +110,8 @@ def pmc_traffic(workload):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r*_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 x2 FETCH correction applied).  Counters need
     their own serialised profiler passes, so they cannot be collected inside a timed bench run; null for other workloads."""
-    if workload != "tiny_b64_bf16":
-        return None
-    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    files = {"tiny_b64_bf16enc_f32dec": ("r3_pmc_traffic.json",), "tiny_b64_bf16": ("r2_pmc_traffic.json", "r1_pmc_traffic.json")}
+    for name in files.get(workload, ()):
         path = os.path.join(ROOT, "profiles", name)
         try:
             ks = json.load(open(path))["kernels"]
@@ -287,7 +303,7 @@ def ladder_entry(name, rank, world, local, weights_cache, depth):
         seq, _ = b.timed(2, 1)
         k = b.kernel_timings(x4=False)
         rtf, tok = b.rates(dt, n, DECODE_STEPS + 1)
-        return {"workload": name, "operands": b.cdt + (" (encoder only; decoder fp32)" if name in DECODER_FP32 else ""), "kv": b.kdt, "utterances": b.B, "steps": n, "ms_per_step": round(dt / n * 1e3, 3),
+        return {"workload": name, "model": b.cfg_name, "operands": b.cdt + (" (encoder only; decoder fp32)" if name in DECODER_FP32 else ""), "kv": b.kdt, "utterances": b.B, "steps": n, "ms_per_step": round(dt / n * 1e3, 3),
                 "value": round(rtf, 1), "tokens_per_sec": round(tok, 1), "unpipelined_ms_per_step": round(seq / 2 * 1e3, 3),
                 "decode_step": k["decode_step"], "cross_attention": {k2: k["roofline"][k2] for k2 in ("achieved", "frac", "us_per_launch")},
                 "encoder": k["encoder"]}
@@ -300,7 +316,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)  # a multiple of the pipeline depth: passes complete in groups of four
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--workload", default="tiny_b64_bf16", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-x4", action="store_true", help="skip the four-chains-in-flight decode step timing (profiler runs: keeps every launch of the dominant kernel alone on the chip)")
@@ -342,6 +358,12 @@ def main():
         b.run_steps(1, 1)
         seq_dt, _ = b.timed(args.steps, 1)
         extras["unpipelined"] = {"ms_per_step": round(seq_dt / args.steps * 1e3, 3), "value": round(b.rates(seq_dt, args.steps, 1)[0], 1)}
+    if world == 1:
+        # the decode step as a pass really runs it (cache length growing 4 .. 103): synchronous passes with and without the loop
+        b.run_steps(1, 1, max_loop=0)
+        t_full, _ = b.timed(3, 1, gather=False)
+        t_none, _ = b.timed(3, 1, max_loop=0, gather=False)
+        extras["_in_pass_step_us"] = (t_full - t_none) / 3 / DECODE_STEPS * 1e6
     if world == 1 and not args.no_extras:
         log("H2D-inclusive leg")
         b.run_steps(min(depth, args.steps), depth, mel=b.mel_host)
@@ -365,21 +387,26 @@ def main():
         rtf, tok_s = b.rates(dt, args.steps, DECODE_STEPS + 1)
         log("kernel timings (cross-attention, decode step, encoder)")
         k = b.kernel_timings(x4=not args.no_x4)
+        dtype, prec = precision_of(args.workload, b.cdt, b.kdt)
         res = {
             "metric": "real-time-factor (audio-sec/wall-sec)", "value": round(rtf, 1), "unit": "x real-time",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": b.cdt, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "tokens_per_sec": round(tok_s, 1),
             "config": {"workload": f"whisper-{b.cfg_name}, {b.B} synthetic 80x3000 mels per GPU ({b.total} total) resident in HBM, greedy, "
-                                   f"1 prefill + {DECODE_STEPS} decode steps; GEMM operands {b.cdt} in the encoder AND the decoder (weights, "
-                                   f"activations fed to MFMA), KV cache {b.kdt} — narrower than BASELINE config 3's wording ('bf16 encoder "
-                                   "GEMMs'): see precision_ladder for the fp32-KV and all-fp32 runs; accumulation / LayerNorm / softmax / "
-                                   "residual fp32; random-init weights (seed 0)",
+                                   f"1 prefill + {DECODE_STEPS} decode steps; {prec}; accumulation / LayerNorm / softmax / residual fp32; "
+                                   "random-init weights (seed 0)",
                        "name": args.workload, "utterances_per_gpu": b.B, "kv_dtype": b.kdt, "parallelism": f"dp{world}",
                        "pipeline_depth": depth},
         }
+        in_pass = extras.pop("_in_pass_step_us", None)
         res.update(extras)
         res.update(k)
+        if in_pass is not None:  # next to the replayed step (cache length held at 50): the average over a real pass's 99 steps
+            sb = res["decode_step"]["algorithmic_bytes"]
+            res["decode_step"]["cache_len"] = 50
+            res["decode_step"]["in_pass_avg_us"] = round(in_pass, 1)
+            res["decode_step"]["in_pass_frac_of_hbm_peak"] = round(sb / (in_pass * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         if world == 1 and not args.no_extras:
             res["precision_ladder"] = []
             for name in LADDER:
@@ -388,6 +415,10 @@ def main():
                 log(f"precision ladder: {name}")
                 b.model.close()  # one model resident at a time
                 res["precision_ladder"].append(ladder_entry(name, rank, world, local, weights_cache, depth))
+                if name == "tiny_b64_bf16":  # round 2's headline, kept as a named extra: NOT config 3 (decoder and KV narrowed too)
+                    e = res["precision_ladder"][-1]
+                    res["value_all_16bit"] = {"value": e["value"], "ms_per_step": e["ms_per_step"], "steps": e["steps"],
+                                              "note": "bf16 operands in the decoder too + bf16 KV cache: narrower than BASELINE config 3"}
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline (oracle) ...")
             res["cpu_baseline"] = cpu_baseline(b.cfg, b.weights, b.mel_host[0], DECODE_STEPS)

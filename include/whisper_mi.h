@@ -72,6 +72,13 @@ typedef struct wm_state wm_state;
 
 const char* wm_last_error(void);
 
+/* wm_config and wm_decode_opts have grown round by round (decoder_fp32, the timestamp fields) and carry no size field: a host
+ * built against an older header would hand the library structs whose tail it never wrote.  WM_ABI_VERSION is bumped with every
+ * such change; a host binding compares it with wm_abi_version() once after loading the library and refuses a mismatch (the
+ * Python and C++ mirrors do). */
+#define WM_ABI_VERSION 3
+int wm_abi_version(void);
+
 /* ---- WeightLoader(filename) + Whisper() + Whisper.load(loader)   loader.mojo:10-27, whisper.mojo:175-182 ----
  * path: the reference's headerless little-endian fp32 file (order of export_weights.py:19-90).  Unlike the
  * reference (loader.mojo:21-27 reads past the end silently) the byte size is validated: WM_E_SIZE. */

@@ -27,6 +27,12 @@ namespace whisper_mi {
 inline void check(int rc) {
     if (rc != 0) throw std::runtime_error(std::string("whisper_mi: ") + wm_last_error());
 }
+// the structs this header fills are WM_ABI_VERSION's: a library of another version would read tails this host never wrote
+inline void check_abi() {
+    if (wm_abi_version() != WM_ABI_VERSION)
+        throw std::runtime_error("whisper_mi: libwhispermi.so speaks ABI version " + std::to_string(wm_abi_version()) + ", this header " +
+                                 std::to_string(WM_ABI_VERSION));
+}
 
 // whisper.mojo:9-37
 struct WhisperConfig {
@@ -92,11 +98,13 @@ public:
 
     // whisper.load(loader)  (whisper.mojo:180-182, main.mojo:16-17)
     void load(const WeightLoader& loader) {
+        check_abi();
         if (model_) wm_model_free(model_), model_ = nullptr;
         check(wm_model_load(loader.filename().c_str(), &wcfg_, device_, &model_));
     }
     // weights already in memory (flat fp32, the file's order)
     void load(const float* weights, size_t n_floats) {
+        check_abi();
         if (model_) wm_model_free(model_), model_ = nullptr;
         check(wm_model_load_memory(weights, n_floats, &wcfg_, device_, &model_));
     }

@@ -9,7 +9,7 @@ w = np.empty(cfg.weight_count(), np.float32); d = cfg.dims()
 L.wm_synth_weights(C.byref(d), 0, w.ctypes.data_as(C.POINTER(C.c_float)))
 mel = np.empty((B, 80, 3000), np.float32)
 for i in range(B): L.wm_synth_mel_host(1000 + i, 80, 3000, mel[i].ctypes.data_as(C.POINTER(C.c_float)))
-m = Whisper(cfg, compute_dtype=DT_BF16, max_batch=B); m.load(WeightLoader.from_array(w))
+m = Whisper(cfg, compute_dtype=DT_BF16, kv_dtype=(0 if os.environ.get('WM_DEC_F32') else DT_BF16), max_batch=B, decoder_fp32=bool(os.environ.get('WM_DEC_F32'))); m.load(WeightLoader.from_array(w))
 st = C.c_void_p(); _lib.check(L.wm_state_new(m._h, B, C.byref(st)))
 _lib.check(L.wm_encode(m._h, st, mel.ctypes.data_as(C.c_void_p), 0, B, None))
 us = C.c_float()

@@ -15,12 +15,13 @@ if os.environ.get("WM_USE_DEV_LIB") and os.environ.get("WM_DEV_LIB_PATH"):  # a 
 
 # every symbol include/whisper_mi.h declares (tests/test_cabi_symbols.py checks the .so exports all of them)
 SYMBOLS = [
-    "wm_last_error", "wm_model_load", "wm_model_load_memory", "wm_model_free", "wm_weight_count", "wm_weights_convert_v2", "wm_weights_read", "wm_state_new",
+    "wm_last_error", "wm_abi_version", "wm_model_load", "wm_model_load_memory", "wm_model_free", "wm_weight_count", "wm_weights_convert_v2", "wm_weights_read", "wm_state_new",
     "wm_state_reset", "wm_state_free", "wm_state_len", "wm_encode", "wm_state_set_encoder_output", "wm_decode_step",
     "wm_transcribe", "wm_transcribe_submit", "wm_transcribe_wait", "wm_log_mel", "wm_transcribe_pcm", "wm_op_matmul_nt", "wm_op_mlp_block", "wm_op_attention", "wm_op_attention_cached", "wm_op_layer_norm", "wm_op_gelu", "wm_op_softmax_rows", "wm_op_conv1d_k3",
     "wm_op_argmax", "wm_bench_kernel", "wm_bench_bytes", "wm_synth_weights", "wm_synth_mel_host",
 ]
 
+ABI_VERSION = 3  # include/whisper_mi.h WM_ABI_VERSION: the struct layouts below are this version's
 KERNEL_CROSS_ATTN, KERNEL_DECODE_STEP, KERNEL_ENCODER, KERNEL_DECODE_STEP_SHARED = 0, 1, 2, 3
 
 
@@ -54,6 +55,10 @@ def lib():
     L = C.CDLL(LIB_PATH)
     fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p
     L.wm_last_error.restype = C.c_char_p
+    if not hasattr(L, "wm_abi_version") or L.wm_abi_version() != ABI_VERSION:
+        got = L.wm_abi_version() if hasattr(L, "wm_abi_version") else "none"
+        raise WhisperMiError(f"{LIB_PATH} speaks ABI version {got}, this binding {ABI_VERSION}: rebuild the library "
+                             "(python __graft_entry__.py build)")
     L.wm_model_load.argtypes = [C.c_char_p, C.POINTER(WmConfig), C.c_int, C.POINTER(vp)]
     L.wm_model_load_memory.argtypes = [fp, C.c_size_t, C.POINTER(WmConfig), C.c_int, C.POINTER(vp)]
     L.wm_model_free.argtypes = [vp]

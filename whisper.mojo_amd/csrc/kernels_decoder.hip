@@ -237,7 +237,7 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
     WM_DL_STAMP(5);
 }
 #undef WM_DL_STAMP
-template <typename TW, int KPW> static void launch_dec_linear_t(const DecLinearParams& p, int nw, hipStream_t st) {
+template <typename TW, int KPW> static int launch_dec_linear_t(const DecLinearParams& p, int nw, hipStream_t st) {
     // two column tiles per workgroup for the wide projections (QKV, fc1): half the workgroups, one activation
     // fragment (and one LayerNorm) feeding two MFMAs
     static const int nt_force = wm_env("WM_LIN_NT") ? atoi(wm_env("WM_LIN_NT")) : 0;  // dev A/B
@@ -260,6 +260,7 @@ template <typename TW, int KPW> static void launch_dec_linear_t(const DecLinearP
         else
             hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, false, 1>), grid, block, smem(1), st, p);
     }
+    return WM_LAUNCH_OK;
 }
 // K % 32 == 0 and (K/32) must factor as NW * KPW with NW <= 16, KPW <= 4 (true for every K = 128·j, j <= 16).
 static int dec_linear_waves(int K, int elem_bytes = 2) {
@@ -281,13 +282,12 @@ static int dec_linear_waves(int K, int elem_bytes = 2) {
     return 0;
 }
 bool dec_linear_supports_k(int K) { return dec_linear_waves(K) > 0; }
-template <typename TW> void launch_dec_linear(const DecLinearParams& p, hipStream_t st) {
+template <typename TW> int launch_dec_linear(const DecLinearParams& p, hipStream_t st) {
+    if (p.B <= 0 || p.N <= 0) return launch_refuse("dec_linear: empty problem");
     const int ksteps = p.K >> 5;
     const int nw = dec_linear_waves(p.K, (int)sizeof(TW));
-    if (nw == 0) {  // never reached through the C-ABI (check_cfg / wm_op_matmul_nt pad K): refuse rather than drop k-steps
-        fprintf(stderr, "[whispermi] dec_linear: K = %d cannot be split over the waves of a workgroup — launch skipped\n", p.K);
-        return;
-    }
+    if (nw == 0)  // refuse rather than drop k-steps (check_cfg / wm_op_matmul_nt keep model paths away from here)
+        return launch_refuse("dec_linear: K must be a multiple of 32 whose k-steps split over <= 16 waves x <= 4 steps (K <= 2048)");
     switch (ksteps / nw) {
         case 1: return launch_dec_linear_t<TW, 1>(p, nw, st);
         case 2: return launch_dec_linear_t<TW, 2>(p, nw, st);
@@ -295,9 +295,9 @@ template <typename TW> void launch_dec_linear(const DecLinearParams& p, hipStrea
         default: return launch_dec_linear_t<TW, 4>(p, nw, st);
     }
 }
-template void launch_dec_linear<float>(const DecLinearParams&, hipStream_t);
-template void launch_dec_linear<bf16>(const DecLinearParams&, hipStream_t);
-template void launch_dec_linear<f16>(const DecLinearParams&, hipStream_t);
+template int launch_dec_linear<float>(const DecLinearParams&, hipStream_t);
+template int launch_dec_linear<bf16>(const DecLinearParams&, hipStream_t);
+template int launch_dec_linear<f16>(const DecLinearParams&, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------------------
 // Final LayerNorm + tied-embedding logits (whisper.mojo:156-166): logits[B, V] = LN(x)[B, d] · tok_emb[V, d]ᵀ.
@@ -609,16 +609,23 @@ int dec_logits_parts(int N) {
     const int tiles = (N + 15) / 16, ct = dec_logits_tiles_per_wg(N);
     return (tiles + ct - 1) / ct;
 }
-template <typename TW, int KD, int NRB> static void launch_dec_logits_t(const DecLinearParams& p, hipStream_t st) {
+template <typename TW, int KD, int NRB> static int launch_dec_logits_t(const DecLinearParams& p, hipStream_t st) {
     const size_t lds = (size_t)NRB * 16 * (KD * 128 + (sizeof(TW) == 2 ? 80 : 16 / sizeof(TW))) * sizeof(TW);
-    if (lds > 48 * 1024) (void)ensure_dyn_lds(&dec_logits_kernel<TW, KD, NRB>, (int)lds);  // a failure surfaces through hipGetLastError
+    if (lds > 48 * 1024)
+        if (const hipError_t e = ensure_dyn_lds<&dec_logits_kernel<TW, KD, NRB>>((int)lds); e != hipSuccess)
+            return launch_hip_failed("logits kernel: dynamic LDS attribute", e);
     const int ct = dec_logits_tiles_per_wg(p.N);
     dim3 grid(dec_logits_parts(p.N), (p.B + NRB * 16 - 1) / (NRB * 16));
     hipLaunchKernelGGL((dec_logits_kernel<TW, KD, NRB>), grid, dim3(512), lds, st, p, ct);
+    return WM_LAUNCH_OK;
 }
 // requires ln_g/ln_b, no bias/act/residual, K in {128, 384, 512}, ldo % 4 == 0; amax_stride >= dec_logits_parts(N)
-template <typename TW> void launch_dec_logits(const DecLinearParams& p, hipStream_t st) {
+template <typename TW> int launch_dec_logits(const DecLinearParams& p, hipStream_t st) {
     const int kd = p.K >> 7;
+    if (p.B <= 0 || p.N <= 0) return launch_refuse("dec_logits: empty problem");
+    if ((p.K & 127) != 0 || (kd != 1 && kd != 3 && kd != 4)) return launch_refuse("dec_logits: d_model must be 128, 384 or 512");
+    if (!p.ln_g || !p.ln_b) return launch_refuse("dec_logits: the final LayerNorm's gamma / beta are required");
+    if (p.amax_val && p.amax_stride < dec_logits_parts(p.N)) return launch_refuse("dec_logits: amax_stride is smaller than the partials per utterance");
     if (p.B <= 16) {
         if (kd == 1) return launch_dec_logits_t<TW, 1, 1>(p, st);
         if (kd == 3) return launch_dec_logits_t<TW, 3, 1>(p, st);
@@ -628,9 +635,9 @@ template <typename TW> void launch_dec_logits(const DecLinearParams& p, hipStrea
     if (kd == 3) return launch_dec_logits_t<TW, 3, 4>(p, st);
     return launch_dec_logits_t<TW, 4, 4>(p, st);
 }
-template void launch_dec_logits<float>(const DecLinearParams&, hipStream_t);
-template void launch_dec_logits<bf16>(const DecLinearParams&, hipStream_t);
-template void launch_dec_logits<f16>(const DecLinearParams&, hipStream_t);
+template int launch_dec_logits<float>(const DecLinearParams&, hipStream_t);
+template int launch_dec_logits<bf16>(const DecLinearParams&, hipStream_t);
+template int launch_dec_logits<f16>(const DecLinearParams&, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------------------
 // Single-query attention over the KV cache (layers.mojo:186-272), all heads of one utterance per workgroup so that
@@ -788,10 +795,13 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(AttnDecParams p) {
         }
     }
 }
-template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStream_t st) {
+template <typename TKV> int launch_attn_decode(const AttnDecParams& p, hipStream_t st) {
     constexpr int LPH = sizeof(TKV) == 4 ? 16 : 8;
     constexpr bool FAST = sizeof(TKV) == 2;
     const int LPR = p.H * LPH;
+    if (p.B <= 0 || p.H <= 0 || LPR > 256 || p.d != p.H * 64) return launch_refuse("attn_decode: needs 1 <= heads <= 16 of 64 dims (d = 64 heads)");
+    if (p.nsplit < 1 || (!p.direct_out && (!p.part_o || !p.part_ml)) || (p.direct_out && p.nsplit != 1))
+        return launch_refuse("attn_decode: partial buffers / direct output do not match nsplit");
     AttnDecParams q = p;
     // rows swept per step.  16-bit K/V: 256 threads (512 measured no better for the short self-attention: 5.3 vs 5.0 us).
     // fp32 K/V rows are twice as wide (96-128 lanes per row): the latency-bound self-attention takes 512 threads so a
@@ -808,20 +818,22 @@ template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStrea
     if (p.n_keys >= 0 && p.nq == 4) {  // prompt prefill, four positions per utterance from one K/V sweep (q_B = utterances)
         const dim3 grid4(p.nsplit, p.q_B);
         hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 4, 4>), grid4, block, 0, st, q);  // U = 4 as in the step kernel: same arithmetic per query
-        return;
+        return WM_LAUNCH_OK;
     }
     if (p.n_keys >= 0 && !nt_off) {  // the cross-attention K/V stream (1500 rows per utterance, read once per step)
         // p.lds_pad: unused dynamic LDS that caps the workgroups per CU (160 KB / (20 KB static + pad)) — see AttnDecParams
         static const int pad_env = wm_env("WM_ATTN_LDS_PAD") ? atoi(wm_env("WM_ATTN_LDS_PAD")) : -1;  // dev A/B override
         const int lds_pad = pad_env >= 0 ? pad_env : p.lds_pad;
-        if (lds_pad > 40 * 1024) (void)ensure_dyn_lds(&attn_decode_kernel<TKV, LPH, FAST, true, 4>, lds_pad);
+        if (lds_pad > 40 * 1024)
+            if (const hipError_t e = ensure_dyn_lds<&attn_decode_kernel<TKV, LPH, FAST, true, 4>>(lds_pad); e != hipSuccess)
+                return launch_hip_failed("attn_decode: dynamic LDS attribute", e);
 #ifdef WM_DEV
         if (u_cross == 8) {
             hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 8>), grid, block, 0, st, q);
-            return;
+            return WM_LAUNCH_OK;
         } else if (u_cross == 2) {
             hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, true, 2>), grid, block, 0, st, q);
-            return;
+            return WM_LAUNCH_OK;
         }
 #endif
         (void)u_cross;
@@ -833,15 +845,16 @@ template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStrea
         static const int u_self = wm_env("WM_SELF_U") ? atoi(wm_env("WM_SELF_U")) : 4;
         if (u_self == 2) {
             hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, false, 2>), grid, block, 0, st, q);
-            return;
+            return WM_LAUNCH_OK;
         }
 #endif
         hipLaunchKernelGGL((attn_decode_kernel<TKV, LPH, FAST, false, 4>), grid, block, 0, st, q);
     }
+    return WM_LAUNCH_OK;
 }
-template void launch_attn_decode<float>(const AttnDecParams&, hipStream_t);
-template void launch_attn_decode<bf16>(const AttnDecParams&, hipStream_t);
-template void launch_attn_decode<f16>(const AttnDecParams&, hipStream_t);
+template int launch_attn_decode<float>(const AttnDecParams&, hipStream_t);
+template int launch_attn_decode<bf16>(const AttnDecParams&, hipStream_t);
+template int launch_attn_decode<f16>(const AttnDecParams&, hipStream_t);
 
 // merge the key-chunk partials: out[b][h*64+e] = Σ_s w_s·o_s / Σ_s w_s·l_s,  w_s = exp(m_s − max m).
 // One wave per (utterance, head): lane s owns chunk s's (m, l) — one exp per chunk, not per element — and the

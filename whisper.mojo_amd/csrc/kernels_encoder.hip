@@ -8,9 +8,24 @@
 
 #include <algorithm>
 #include <type_traits>
+#include <cstdio>
 #include <cstdlib>
 
 namespace wm {
+
+// ---- launcher status (wm_kernels.h) ------------------------------------------------------------------------------
+static thread_local const char* g_refusal = "";
+static thread_local char g_refusal_buf[256];
+const char* launch_last_refusal() { return g_refusal; }
+int launch_refuse(const char* why) {
+    g_refusal = why;
+    return WM_LAUNCH_BAD_SHAPE;
+}
+int launch_hip_failed(const char* what, hipError_t e) {
+    snprintf(g_refusal_buf, sizeof g_refusal_buf, "%s: %s", what, hipGetErrorString(e));
+    g_refusal = g_refusal_buf;
+    return WM_LAUNCH_HIP;
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // mel [B][C][L] fp32 (channel-major, sample_input.bin layout) -> token-major, zero-padded [B][L+2][Cp] T.
@@ -540,7 +555,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_nt_rowpanel_kernel(GemmParams
 #endif
 #undef WM_RP_STAMP
 }
-template <typename T, typename TO, int KS, bool LNA, int NW> static void launch_rowpanel_t(const GemmParams& p, hipStream_t st) {
+template <typename T, typename TO, int KS, bool LNA, int NW> static int launch_rowpanel_t(const GemmParams& p, hipStream_t st) {
     const int n_units = ((p.M + NW * 32 - 1) / (NW * 32)) * (p.N / 128);
     static const int grid_env = wm_env("WM_RP_GRID") ? atoi(wm_env("WM_RP_GRID")) : 0;
     const int grid = std::min(n_units, grid_env > 0 ? grid_env : (NW == 4 ? 512 : 256));  // two 64-KB-ring workgroups per CU, or one of 128 KB
@@ -548,10 +563,12 @@ template <typename T, typename TO, int KS, bool LNA, int NW> static void launch_
 #ifdef WM_DEV
     lds += 96 * 8;  // phase stamps
 #endif
-    (void)ensure_dyn_lds(&gemm_nt_rowpanel_kernel<T, TO, KS, LNA, NW>, NW == 4 ? 80 * 1024 : 144 * 1024);  // per device; a failure surfaces through hipGetLastError
+    if (const hipError_t e = ensure_dyn_lds<&gemm_nt_rowpanel_kernel<T, TO, KS, LNA, NW>>(NW == 4 ? 80 * 1024 : 144 * 1024); e != hipSuccess)
+        return launch_hip_failed("row-panel GEMM: dynamic LDS attribute", e);
     hipLaunchKernelGGL((gemm_nt_rowpanel_kernel<T, TO, KS, LNA, NW>), dim3(grid), dim3(NW * 64), lds, st, p, n_units);
+    return WM_LAUNCH_OK;
 }
-template <typename T, typename TO, int KS> static void launch_rowpanel(const GemmParams& p, hipStream_t st) {
+template <typename T, typename TO, int KS> static int launch_rowpanel(const GemmParams& p, hipStream_t st) {
     // 128-row panels, two workgroups per CU.  The 8-wave shape (256-row panels: half the W traffic and DMA instructions per MFMA)
     // measured the same on one box (encoder 4.24 vs 4.23 ms): W staging is not what bounds this kernel.  Developer A/B only.
 #ifdef WM_DEV
@@ -561,7 +578,7 @@ template <typename T, typename TO, int KS> static void launch_rowpanel(const Gem
     }
 #endif
     if (p.ln_g) return launch_rowpanel_t<T, TO, KS, true, 4>(p, st);
-    launch_rowpanel_t<T, TO, KS, false, 4>(p, st);
+    return launch_rowpanel_t<T, TO, KS, false, 4>(p, st);
 }
 static bool rowpanel_ok(int operand_bytes, const GemmParams& p, int batch) {
     // A-stationary row-panel kernel: plain [M,K]x[N,K] (no conv batching), K = 384 (K = 512 needs 128 A registers: spills), no addends, N <= 3072
@@ -866,33 +883,35 @@ bool gemm_nt_fuses_layernorm_out(int operand_bytes, const GemmParams& p) {
     static const bool off = wm_env("WM_GEMM_NO_LN_OUT") != nullptr;
     return !off && fullrow_ok(operand_bytes, p);
 }
-template <typename T, bool LNO, bool ACT> static void launch_fullrow_t(const GemmParams& p, int batch, hipStream_t st) {
+template <typename T, bool LNO, bool ACT> static int launch_fullrow_t(const GemmParams& p, int batch, hipStream_t st) {
     const int lds = 4 * 256 * 64 * (int)sizeof(T);  // 128 KB: one workgroup per CU
     dim3 grid((p.M + 127) / 128, batch);
-    (void)ensure_dyn_lds(&gemm_nt_fullrow_kernel<T, LNO, ACT>, lds);  // per device; a failure surfaces through hipGetLastError
+    if (const hipError_t e = ensure_dyn_lds<&gemm_nt_fullrow_kernel<T, LNO, ACT>>(lds); e != hipSuccess)
+        return launch_hip_failed("full-row GEMM: dynamic LDS attribute", e);
     hipLaunchKernelGGL((gemm_nt_fullrow_kernel<T, LNO, ACT>), grid, dim3(512), lds, st, p);
+    return WM_LAUNCH_OK;
 }
-template <typename T> static void launch_fullrow(const GemmParams& p, int batch, hipStream_t st) {
+template <typename T> static int launch_fullrow(const GemmParams& p, int batch, hipStream_t st) {
     if (p.lno_out) {
         if (p.act) return launch_fullrow_t<T, true, true>(p, batch, st);
         return launch_fullrow_t<T, true, false>(p, batch, st);
     }
     if (p.act) return launch_fullrow_t<T, false, true>(p, batch, st);
-    launch_fullrow_t<T, false, false>(p, batch, st);
+    return launch_fullrow_t<T, false, false>(p, batch, st);
 }
 
-template <typename T, typename TO> void launch_gemm_nt(const GemmParams& p, int batch, hipStream_t st) {
-    if (p.ln_g && !rowpanel_ok((int)sizeof(T), p, batch)) {  // caller bug (see gemm_nt_fuses_layernorm): refuse rather than multiply un-normalised rows
-        fprintf(stderr, "[whispermi] gemm_nt: fused LayerNorm asked of a shape only the plain kernels take - launch skipped\n");
-        return;
-    }
+// Refusals (nothing is launched, WM_LAUNCH_BAD_SHAPE): a fused LayerNorm asked of a shape whose kernel cannot apply it — the result
+// would be a product of un-normalised rows / a missing operand copy — and shapes no kernel tiles (N % 128, K % 32).
+template <typename T, typename TO> int launch_gemm_nt(const GemmParams& p, int batch, hipStream_t st) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || batch <= 0) return launch_refuse("gemm_nt: empty problem");
+    if ((p.N & 127) != 0) return launch_refuse("gemm_nt: N must be a multiple of 128 (the dense kernels tile 128 output columns)");
+    if ((p.K & 31) != 0) return launch_refuse("gemm_nt: K must be a multiple of 32 (one MFMA k-step)");
+    if (p.ln_g && !rowpanel_ok((int)sizeof(T), p, batch))  // caller bug (see gemm_nt_fuses_layernorm)
+        return launch_refuse("gemm_nt: LayerNorm fused into the A load asked of a shape only the plain kernels take");
     if constexpr (sizeof(T) == 2 && sizeof(TO) == 4) {
         if (fullrow_ok(2, p)) return launch_fullrow<T>(p, batch, st);
     }
-    if (p.lno_out) {
-        fprintf(stderr, "[whispermi] gemm_nt: fused output LayerNorm asked of a shape the full-row kernel does not take - launch skipped\n");
-        return;
-    }
+    if (p.lno_out) return launch_refuse("gemm_nt: LayerNorm of the output rows asked of a shape the full-row kernel does not take");
     dim3 grid(p.N / 128, (p.M + 127) / 128, batch);
     static const bool no_lds = wm_env("WM_GEMM_DIRECT") != nullptr;
     if constexpr (sizeof(T) == 2) {
@@ -902,10 +921,11 @@ template <typename T, typename TO> void launch_gemm_nt(const GemmParams& p, int 
             GemmParams q = p;
             q.xcd_remap = !no_remap;
             hipLaunchKernelGGL((gemm_nt_lds_kernel<T, TO>), grid, dim3(256), 0, st, q);
-            return;
+            return WM_LAUNCH_OK;
         }
     }
     hipLaunchKernelGGL((gemm_nt_kernel<T, TO>), grid, dim3(256), 0, st, p);
+    return WM_LAUNCH_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1378,10 +1398,10 @@ void launch_flash_attn_enc(const void* qkv, void* out, int B, int H, int n_ctx, 
 WM_INST_T(float)
 WM_INST_T(bf16)
 WM_INST_T(f16)
-template void launch_gemm_nt<float, float>(const GemmParams&, int, hipStream_t);
-template void launch_gemm_nt<bf16, float>(const GemmParams&, int, hipStream_t);
-template void launch_gemm_nt<bf16, bf16>(const GemmParams&, int, hipStream_t);
-template void launch_gemm_nt<f16, float>(const GemmParams&, int, hipStream_t);
-template void launch_gemm_nt<f16, f16>(const GemmParams&, int, hipStream_t);
+template int launch_gemm_nt<float, float>(const GemmParams&, int, hipStream_t);
+template int launch_gemm_nt<bf16, float>(const GemmParams&, int, hipStream_t);
+template int launch_gemm_nt<bf16, bf16>(const GemmParams&, int, hipStream_t);
+template int launch_gemm_nt<f16, float>(const GemmParams&, int, hipStream_t);
+template int launch_gemm_nt<f16, f16>(const GemmParams&, int, hipStream_t);
 
 }  // namespace wm

@@ -47,6 +47,14 @@ static int fail(int code, const char* fmt, ...) {
     } while (0)
 
 extern "C" const char* wm_last_error(void) { return g_err.c_str(); }
+extern "C" int wm_abi_version(void) { return WM_ABI_VERSION; }
+
+// a launcher's status (wm_kernels.h WM_LAUNCH_*) as a C-ABI status: a refused shape is the caller's argument error
+static int launch_rc(int st) {
+    if (st == wm::WM_LAUNCH_OK) return 0;
+    return fail(st == wm::WM_LAUNCH_HIP ? WM_E_HIP : WM_E_ARG, "%s", wm::launch_last_refusal());
+}
+#define LCHK(expr) WMCHK(launch_rc(expr))
 
 // Developer timeline (WM_TRACE_EVENTS=1): HIP events recorded on the library's streams at pass / phase boundaries and
 // printed, sorted on the GPU clock, when the model is freed.  The profiler serialises concurrent queues; events do not.
@@ -255,10 +263,10 @@ struct wm_state {
         }                                    \
     } while (0)
 
-static void gemm_dispatch(int dt_in, int dt_out, const GemmParams& p, int batch, hipStream_t st);
+static int gemm_dispatch(int dt_in, int dt_out, const GemmParams& p, int batch, hipStream_t st);
 // C = LN(x) W^T (+ epilogue of p): p.A names the scratch for the normalised rows.  The A-stationary GEMM normalises the fp32 rows
 // while it loads them (no LayerNorm launch, no 16-bit copy through HBM); every other shape runs layernorm_rows first.
-static void ln_then_gemm(int dt_in, int dt_out, GemmParams p, const float* x, const float* g, const float* b, hipStream_t st) {
+static int ln_then_gemm(int dt_in, int dt_out, GemmParams p, const float* x, const float* g, const float* b, hipStream_t st) {
     if (gemm_nt_fuses_layernorm(dt_in == WM_F32 ? 4 : 2, p, 1)) {
         p.A = x;
         p.ln_g = g;
@@ -266,22 +274,19 @@ static void ln_then_gemm(int dt_in, int dt_out, GemmParams p, const float* x, co
     } else {
         DISPATCH_DT(dt_in, TT, launch_layernorm_rows<TT>(x, g, b, const_cast<void*>(p.A), nullptr, p.M, p.K, 1e-5f, st));
     }
-    gemm_dispatch(dt_in, dt_out, p, 1, st);
+    return gemm_dispatch(dt_in, dt_out, p, 1, st);
 }
-static void gemm_dispatch(int dt_in, int dt_out, const GemmParams& p, int batch, hipStream_t st) {
+// 0 or a WM_E_* status with wm_last_error set (a shape the kernels refuse: nothing was launched)
+static int gemm_dispatch(int dt_in, int dt_out, const GemmParams& p, int batch, hipStream_t st) {
+    int rc;
     if (dt_in == WM_F32) {
-        launch_gemm_nt<float, float>(p, batch, st);
+        rc = launch_gemm_nt<float, float>(p, batch, st);
     } else if (dt_in == WM_BF16) {
-        if (dt_out == WM_F32)
-            launch_gemm_nt<bf16, float>(p, batch, st);
-        else
-            launch_gemm_nt<bf16, bf16>(p, batch, st);
+        rc = dt_out == WM_F32 ? launch_gemm_nt<bf16, float>(p, batch, st) : launch_gemm_nt<bf16, bf16>(p, batch, st);
     } else {
-        if (dt_out == WM_F32)
-            launch_gemm_nt<f16, float>(p, batch, st);
-        else
-            launch_gemm_nt<f16, f16>(p, batch, st);
+        rc = dt_out == WM_F32 ? launch_gemm_nt<f16, float>(p, batch, st) : launch_gemm_nt<f16, f16>(p, batch, st);
     }
+    return launch_rc(rc);
 }
 
 extern "C" size_t wm_weight_count(const wm_dims* c) { return wm_synth_count(c); }
@@ -855,8 +860,7 @@ static int cross_kv_chunk(wm_model* m, wm_state* s, int c0, int bc, hipStream_t 
     p.bias = m->cross_kv_b.as<float>();
     p.group_n = c.d_model;
     p.group_stride = (long)((size_t)s->B * T * d);
-    gemm_dispatch(m->cfg.compute_dtype, m->cfg.kv_dtype, p, 1, st);
-    return 0;
+    return gemm_dispatch(m->cfg.compute_dtype, m->cfg.kv_dtype, p, 1, st);
 }
 
 static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hipStream_t st) {
@@ -886,7 +890,7 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
             p.bias = m->conv1_b.as<float>();
             p.act = 1;
             p.gelu_mode = m->cfg.gelu_mode;
-            gemm_dispatch(T, T, p, bc, st);
+            WMCHK(gemm_dispatch(T, T, p, bc, st));
         }
         {  // conv2 (stride 2) + GELU + pos_emb -> x   whisper.mojo:78-89
             GemmParams p{};
@@ -911,7 +915,7 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
                 p.lno_out = s->xn.p;
                 xn_is_ln1 = true;
             }
-            gemm_dispatch(T, WM_F32, p, bc, st);
+            WMCHK(gemm_dispatch(T, WM_F32, p, bc, st));
         }
         for (int l = 0; l < c.n_layers; ++l) {  // layers.mojo:435-519 with is_decoder=False
             EncLayer& w = m->enc[l];
@@ -927,9 +931,9 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
             p.ldc = 3 * d;
             p.bias = w.qkv_b.as<float>();
             if (xn_is_ln1)  // the producer of x wrote LN1(x) next to it
-                gemm_dispatch(T, T, p, 1, st);
+                WMCHK(gemm_dispatch(T, T, p, 1, st));
             else
-                ln_then_gemm(T, T, p, s->x.as<float>(), w.ln1_g.as<float>(), w.ln1_b.as<float>(), st);
+                WMCHK(ln_then_gemm(T, T, p, s->x.as<float>(), w.ln1_g.as<float>(), w.ln1_b.as<float>(), st));
             DISPATCH_DT(T, TT, launch_flash_attn_enc<TT>(s->qkv.p, s->ao.p, bc, c.n_heads, c.n_audio_ctx, scale, st));
             GemmParams o{};
             o.A = s->ao.p;
@@ -950,7 +954,7 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
                 o.lno_b = w.ln2_b.as<float>();
                 o.lno_out = s->xn.p;
             }
-            gemm_dispatch(T, WM_F32, o, 1, st);
+            WMCHK(gemm_dispatch(T, WM_F32, o, 1, st));
             GemmParams f1{};
             f1.A = s->xn.p;
             f1.W = w.fc1_w.p;
@@ -965,9 +969,9 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
             f1.act = 1;
             f1.gelu_mode = m->cfg.gelu_mode;
             if (xn_is_ln2)
-                gemm_dispatch(T, T, f1, 1, st);
+                WMCHK(gemm_dispatch(T, T, f1, 1, st));
             else
-                ln_then_gemm(T, T, f1, s->x.as<float>(), w.ln2_g.as<float>(), w.ln2_b.as<float>(), st);
+                WMCHK(ln_then_gemm(T, T, f1, s->x.as<float>(), w.ln2_g.as<float>(), w.ln2_b.as<float>(), st));
             GemmParams f2{};
             f2.A = s->hid.p;
             f2.W = w.fc2_w.p;
@@ -987,7 +991,7 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
                 f2.lno_b = m->enc[l + 1].ln1_b.as<float>();
                 f2.lno_out = s->xn.p;
             }
-            gemm_dispatch(T, WM_F32, f2, 1, st);
+            WMCHK(gemm_dispatch(T, WM_F32, f2, 1, st));
         }
         float* encf = s->enc_f.as<float>() + (size_t)c0 * NT * d;
         DISPATCH_DT(T, TT, launch_layernorm_rows<TT>(s->x.as<float>(), m->enc_ln_g.as<float>(), m->enc_ln_b.as<float>(), s->enc_t.p, encf, M, c.d_model, 1e-5f, st));
@@ -997,11 +1001,12 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
     return 0;
 }
 
+// B < 0: any batch size (the caller takes it from the state AFTER this check — a stale handle is never dereferenced)
 static int check_state(wm_model* m, wm_state* s, int B) {
     if (!m || !s) return fail(WM_E_ARG, "null handle");
     if (!state_is_live(s)) return fail(WM_E_ARG, "stale state handle (its model was freed or reloaded)");
     if (s->m != m) return fail(WM_E_ARG, "state belongs to another model");
-    if (B != s->B) return fail(WM_E_ARG, "B=%d but the state was created for %d", B, s->B);
+    if (B >= 0 && B != s->B) return fail(WM_E_ARG, "B=%d but the state was created for %d", B, s->B);
     return 0;
 }
 
@@ -1043,11 +1048,15 @@ extern "C" int wm_state_set_encoder_output(wm_model* m, wm_state* s, const float
 }
 
 // ---- one decode step for all B utterances: whisper.mojo:130-167 with L_tgt = 1 ------------------------------------
-static void dec_linear_dispatch(int dt, const DecLinearParams& p, hipStream_t st) {
-    DISPATCH_DT(dt, TT, launch_dec_linear<TT>(p, st));
+static int dec_linear_dispatch(int dt, const DecLinearParams& p, hipStream_t st) {
+    int rc = 0;
+    DISPATCH_DT(dt, TT, rc = launch_dec_linear<TT>(p, st));
+    return launch_rc(rc);
 }
-static void attn_decode_dispatch(int dt, const AttnDecParams& p, hipStream_t st) {
-    DISPATCH_DT(dt, TT, launch_attn_decode<TT>(p, st));
+static int attn_decode_dispatch(int dt, const AttnDecParams& p, hipStream_t st) {
+    int rc = 0;
+    DISPATCH_DT(dt, TT, rc = launch_attn_decode<TT>(p, st));
+    return launch_rc(rc);
 }
 
 // A view of `nb` utterances starting at b0, decoding on stream st under control block ctl.
@@ -1058,7 +1067,7 @@ struct DecView {
 };
 static DecView whole_batch(wm_model* m, wm_state* s) { return DecView{0, s->B, m->stream, s->ctl.as<StepCtl>()}; }
 
-static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v, int P = 1) {
+static int launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v, int P = 1) {
     const wm_dims& c = m->cfg.dims;
     const size_t d = c.d_model, ks = dt_size(m->cfg.kv_dtype);
     const size_t cross_l = (size_t)s->B * c.n_audio_ctx * d;
@@ -1083,7 +1092,7 @@ static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v,
     a.ts = (long long*)m->ts_buf.p;
     a.ts_id = s->trace_id;
     a.lds_pad = s->shares_chip ? 34 * 1024 : 0;
-    attn_decode_dispatch(m->cfg.kv_dtype, a, v.st);
+    return attn_decode_dispatch(m->cfg.kv_dtype, a, v.st);
 }
 
 // want_logits: run the final LN + vocabulary projection.  full_logits: also materialise [B, vocab] fp32 (stage tests,
@@ -1092,8 +1101,8 @@ static void launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v,
 // position-major (row = t * B + b), tokens / positions come from tok_rows / pos_rows, K/V rows go to cache rows len + t, the
 // self-attention of position t sees keys 0..len+t (the causal mask of layers.mojo:309-318), logits only for the last
 // position.  Every row's arithmetic is what the single-position pass does for it, so the ids are the same bit for bit.
-static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_logits, bool full_logits = false,
-                        const float* mask = nullptr, int P = 1, bool embed = true, const TsRules* rules = nullptr) {
+static int decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_logits, bool full_logits = false,
+                       const float* mask = nullptr, int P = 1, bool embed = true, const TsRules* rules = nullptr) {
     const wm_dims& c = m->cfg.dims;
     const int T = dec_dtype(m->cfg), KV = m->cfg.kv_dtype;  // T: the decoder's operand dtype
     const int B = v.nb * P;          // activation rows of this pass
@@ -1136,7 +1145,7 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
             p.kv_dtype = KV;
             p.kv_B = qB;
             p.ctl = ctl;
-            dec_linear_dispatch(T, p, st);
+            WMCHK(dec_linear_dispatch(T, p, st));
         }
         {  // self-attention over current_len+1 cached rows   (layers.mojo:186-272)
             AttnDecParams a{};
@@ -1154,10 +1163,10 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
             a.H = c.n_heads;
             a.d = c.d_model;
             a.B = B;
-            attn_decode_dispatch(KV, a, st);
+            WMCHK(attn_decode_dispatch(KV, a, st));
         }
         // the attention outputs and the MLP hidden rows are handed over in operand dtype T (what the next MFMA consumes)
-        auto proj_residual = [&](const float* in, int K, const DevBuf& W, const DevBuf& bias) {  // x += in·Wᵀ + b
+        auto proj_residual = [&](const float* in, int K, const DevBuf& W, const DevBuf& bias) -> int {  // x += in·Wᵀ + b
             DecLinearParams p{};
             p.x = in;
             p.ldx = K;
@@ -1171,9 +1180,9 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
             p.ldr = c.d_model;
             p.out = dx;
             p.ldo = c.d_model;
-            dec_linear_dispatch(T, p, st);
+            return dec_linear_dispatch(T, p, st);
         };
-        proj_residual(dattn, c.d_model, w.so_w, w.so_b);
+        WMCHK(proj_residual(dattn, c.d_model, w.so_w, w.so_b));
         {  // LNx -> cross q
             DecLinearParams p{};
             p.x = dx;
@@ -1187,14 +1196,14 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
             p.bias = w.cq_b.as<float>();
             p.out = dq;
             p.ldo = c.d_model;
-            dec_linear_dispatch(T, p, st);
+            WMCHK(dec_linear_dispatch(T, p, st));
         }
-        launch_cross_attn(m, s, l, v, P);
+        WMCHK(launch_cross_attn(m, s, l, v, P));
         // (merging the chunk partials inside the projection's prologue was measured 14 us per layer SLOWER than this
         // 3 us launch: 96 workgroups each re-reading 295 KB of partials)
         launch_attn_combine(s->part_o.as<float>() + (size_t)v.b0 * s->nsplit * d, s->part_ml.as<float>() + (size_t)v.b0 * s->nsplit * c.n_heads * 2,
                             dattn, T, B, s->nsplit, c.n_heads, c.d_model, st, (long long*)m->ts_buf.p, s->trace_id);
-        proj_residual(dattn, c.d_model, w.co_w, w.co_b);
+        WMCHK(proj_residual(dattn, c.d_model, w.co_w, w.co_b));
         {  // LN2 -> fc1 + GELU
             DecLinearParams p{};
             p.x = dx;
@@ -1211,9 +1220,9 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
             p.out = dhid;
             p.out_is_t = 1;
             p.ldo = c.ffn;
-            dec_linear_dispatch(T, p, st);
+            WMCHK(dec_linear_dispatch(T, p, st));
         }
-        proj_residual(dhid, c.ffn, w.fc2_w, w.fc2_b);
+        WMCHK(proj_residual(dhid, c.ffn, w.fc2_w, w.fc2_b));
     }
     if (want_logits) {  // final LN + tied-embedding logits (whisper.mojo:156-166), no bias
         DecLinearParams p{};
@@ -1241,8 +1250,11 @@ static void decode_core(wm_model* m, wm_state* s, const DecView& v, bool want_lo
         }
         p.ts = (long long*)m->ts_buf.p;
         p.ts_id = s->trace_id;
-        DISPATCH_DT(T, TT, launch_dec_logits<TT>(p, st));
+        int lrc = 0;
+        DISPATCH_DT(T, TT, lrc = launch_dec_logits<TT>(p, st));
+        LCHK(lrc);
     }
+    return 0;
 }
 
 static ArgmaxParams argmax_params(wm_model* m, wm_state* s, const DecView& v, bool record, int eot, int ignore_eot,
@@ -1289,7 +1301,7 @@ static ArgmaxParams argmax_params(wm_model* m, wm_state* s, const DecView& v, bo
 extern "C" int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, int q_len, const int32_t* start_pos,
                               float* logits, int32_t* next) {
     if (!m || !s || !tokens || !start_pos || q_len <= 0) return fail(WM_E_ARG, "bad argument");
-    WMCHK(check_state(m, s, s->B));
+    WMCHK(check_state(m, s, -1));
     if (!s->has_enc) return fail(WM_E_STATE, "no encoder output in this state (call wm_encode first)");
     const wm_dims& c = m->cfg.dims;
     const int B = s->B;
@@ -1313,7 +1325,7 @@ extern "C" int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, i
         HIPCHK(hipMemcpyAsync(s->tok_rows.p, trow.data(), trow.size() * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(s->pos_rows.p, prow.data(), prow.size() * 4, hipMemcpyHostToDevice, st));
         launch_set_step(v.ctl, s->host_len, 1, nullptr, 0, nullptr, 0, B, st);
-        decode_core(m, s, v, true, true, nullptr, q_len);
+        WMCHK(decode_core(m, s, v, true, true, nullptr, q_len));
         HIPCHK(hipGetLastError());         // a launch that failed (bad configuration, LDS attribute) is reported here
         HIPCHK(hipStreamSynchronize(st));  // trow / prow go out of scope
         s->host_len += q_len;
@@ -1327,7 +1339,7 @@ extern "C" int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, i
         HIPCHK(hipMemcpyAsync(s->tok.p, col.data(), B * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(s->pos.p, pos.data(), B * 4, hipMemcpyHostToDevice, st));
         launch_set_step(v.ctl, s->host_len, 1, nullptr, 0, nullptr, 0, B, st);
-        decode_core(m, s, v, i == q_len - 1, true);
+        WMCHK(decode_core(m, s, v, i == q_len - 1, true));
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));  // col/pos are reused next iteration
         s->host_len += 1;
@@ -1406,11 +1418,11 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
         // prefill (whisper.mojo:195, start_pos=0): the q_len = n_prompt causal block equals n_prompt single-token steps
         static const bool seq_prefill = wm_env("WM_SEQ_PREFILL") != nullptr;  // A/B: one pass per prompt position
         if (!seq_prefill && s->lanes.size() == 1 && o->n_prompt > 1 && o->n_prompt <= wm_state::PREFILL_MAX) {
-            decode_core(m, s, v, true, false, s->mask_begin.as<float>(), o->n_prompt, true, rp);  // init_tokens filled tok_rows / pos_rows
+            WMCHK(decode_core(m, s, v, true, false, s->mask_begin.as<float>(), o->n_prompt, true, rp));  // init_tokens filled tok_rows / pos_rows
         } else {
             for (int i = 0; i < o->n_prompt; ++i) {
                 launch_set_step(v.ctl, i, 1, s->pos.as<int>() + v.b0, i, s->tok.as<int>() + v.b0, o->prompt[i], v.nb, v.st);
-                decode_core(m, s, v, i == o->n_prompt - 1, false, s->mask_begin.as<float>(), 1, true, rp);
+                WMCHK(decode_core(m, s, v, i == o->n_prompt - 1, false, s->mask_begin.as<float>(), 1, true, rp));
             }
         }
         launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, false, false, rp), v.st);  // :198-203
@@ -1429,9 +1441,14 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
             }
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(v.st, hipStreamCaptureModeThreadLocal));
-            decode_core(m, s, v, true, false, s->mask_steady.as<float>(), 1, false, rp);
+            const int crc = decode_core(m, s, v, true, false, s->mask_steady.as<float>(), 1, false, rp);
             launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, true, true, rp), v.st);
-            HIPCHK(hipStreamEndCapture(v.st, &g));
+            const hipError_t cap = hipStreamEndCapture(v.st, &g);  // always closed, also when a launcher refused
+            if (crc) {
+                if (g) (void)hipGraphDestroy(g);
+                return crc;
+            }
+            HIPCHK(cap);
             hipError_t ge = hipSuccess;
             for (int k = 0; k < wm_state::Lane::NEXEC && ge == hipSuccess; ++k) ge = hipGraphInstantiate(&ln.graph[k], g, nullptr, nullptr, 0);
             (void)hipGraphDestroy(g);
@@ -1474,7 +1491,8 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
                 }
             } else {
                 const DecView v{ln.b0, ln.nb, ln.st, ln.ctl};
-                decode_core(m, s, v, true, false, s->mask_steady.as<float>(), 1, false, rp);
+                rc = decode_core(m, s, v, true, false, s->mask_steady.as<float>(), 1, false, rp);
+                if (rc) break;
                 launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, true, true, rp), v.st);
             }
         }
@@ -1686,7 +1704,7 @@ static int frontend_run(wm_model* m, const float* pcm, const int32_t* n_samples,
         p.lda = 416;
         p.ldw = 416;
         p.ldc = 512;
-        launch_gemm_nt<float, float>(p, 1, st);
+        LCHK((launch_gemm_nt<float, float>(p, 1, st)));
         launch_mel_log(m->fe.spec.as<float>(), m->fe.fb.as<float>(), m->fe.band.as<int>(), m->fe.logtmp.as<float>() + (size_t)c0 * c.n_mels * n_frames,
                        bc, n_frames, c.n_mels, st);
     }
@@ -1714,6 +1732,9 @@ extern "C" int wm_transcribe_pcm(wm_model* m, const float* pcm, const int32_t* n
 }
 
 // ---- measurement helpers ------------------------------------------------------------------------------------------------
+// A freshly encoded state has an empty self-attention cache; the decode step is priced AND timed mid-sequence, at this many
+// cached rows (SURVEY §8d quotes its byte figures at t = 50; the rows of a fresh cache are zero, which the timing does not care about)
+static const int BENCH_STEP_LEN = 50;
 extern "C" int wm_bench_bytes(wm_model* m, wm_state* s, int which, double* bytes) {
     if (!m || !s || !bytes) return fail(WM_E_ARG, "null argument");
     if (!state_is_live(s) || s->m != m) return fail(WM_E_ARG, "stale or foreign state handle");
@@ -1728,7 +1749,7 @@ extern "C" int wm_bench_bytes(wm_model* m, wm_state* s, int which, double* bytes
         // (fused argmax: only B x ceil(V/128) (value, index) partials are written and re-read)
         const double f = c.ffn, L = c.n_layers, V = c.vocab;
         const double p_blk = 8 * d * d + 2 * f * d + (4 + 4 + 1 + 1 + 6) * d + f;  // 2 attn (4 mats each) + mlp + biases + 3 LN
-        const double t = s->host_len > 0 ? s->host_len : 50;
+        const double t = s->host_len > 0 ? s->host_len : BENCH_STEP_LEN;
         *bytes = ws * (L * (8 * d * d + 2 * f * d) + V * d) + 4 * (L * (p_blk - 8 * d * d - 2 * f * d) + 2 * d) +
                  B * L * 2 * d * ks * (c.n_audio_ctx + t) + B * L * 2 * d * ks + B * s->npart * 8.0 * 2 + B * 4;
     } else if (which == WM_KERNEL_ENCODER) {
@@ -1741,7 +1762,7 @@ extern "C" int wm_bench_bytes(wm_model* m, wm_state* s, int which, double* bytes
 
 extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, float* avg_us) {
     if (!m || !s || !avg_us || reps <= 0) return fail(WM_E_ARG, "bad argument");
-    WMCHK(check_state(m, s, s->B));
+    WMCHK(check_state(m, s, -1));
     if (!s->has_cross) return fail(WM_E_STATE, "state has no cross K/V (call wm_encode first)");
     HIPCHK(hipSetDevice(m->device));
     hipStream_t st = m->stream;
@@ -1751,27 +1772,32 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
     const int L = m->cfg.dims.n_layers;
     if (which == WM_KERNEL_CROSS_ATTN) {
         const DecView v = whole_batch(m, s);
-        for (int i = 0; i < L; ++i) launch_cross_attn(m, s, i, v);  // warm-up
+        for (int i = 0; i < L; ++i) WMCHK(launch_cross_attn(m, s, i, v));  // warm-up
         HIPCHK(hipEventRecord(e0, st));
-        for (int i = 0; i < reps; ++i) launch_cross_attn(m, s, i % L, v);  // cycles the layers: 4 x 295 MB > 256 MB L3
+        for (int i = 0; i < reps; ++i) WMCHK(launch_cross_attn(m, s, i % L, v));  // cycles the layers: 4 x 295 MB > 256 MB L3
         HIPCHK(hipEventRecord(e1, st));
     } else if (which == WM_KERNEL_DECODE_STEP || which == WM_KERNEL_DECODE_STEP_SHARED) {
         s->shares_chip = which == WM_KERNEL_DECODE_STEP_SHARED;  // the K/V stream as pipelined passes launch it
         // on the state's own decode stream, as the transcribe loop runs it: several states can be timed concurrently
         // from several host threads (bench.py: four chains in flight)
-        const int len0 = std::max(s->host_len, 1);
+        const int len0 = s->host_len > 0 ? s->host_len : BENCH_STEP_LEN;  // the cache length wm_bench_bytes prices
         HIPCHK(hipStreamSynchronize(m->stream));  // wm_encode ran there
         const bool own = s->lanes.size() == 1;      // (WM_DEC_LANES > 1: whole batch on the model stream as before)
         if (own) st = s->lanes[0].st;
         const DecView v{0, s->B, st, own ? s->lanes[0].ctl : s->ctl.as<StepCtl>()};
         launch_set_step(v.ctl, len0, 1, nullptr, 0, nullptr, 0, s->B, st);
-        decode_core(m, s, v, true);
+        WMCHK(decode_core(m, s, v, true));
         // timed as the transcribe loop runs it: a captured graph of the step, replayed (cache length held constant)
         hipGraph_t g = nullptr;
         hipGraphExec_t ge = nullptr;
         HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        decode_core(m, s, v, true);
-        HIPCHK(hipStreamEndCapture(st, &g));
+        const int crc = decode_core(m, s, v, true);
+        const hipError_t cap = hipStreamEndCapture(st, &g);
+        if (crc) {
+            if (g) (void)hipGraphDestroy(g);
+            return crc;
+        }
+        HIPCHK(cap);
         HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         (void)hipGraphDestroy(g);
         HIPCHK(hipGraphLaunch(ge, st));
@@ -1800,10 +1826,10 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
             p.residual = s->dx.as<float>(); p.ldr = c.d_model; p.out = s->dx.as<float>(); p.ldo = c.d_model;
         }
         launch_set_step(s->ctl.as<StepCtl>(), 10, 1, nullptr, 0, nullptr, 0, s->B, st);
-        for (int i = 0; i < 3; ++i) { dec_linear_dispatch(T, p, st); launch_cross_attn(m, s, i, whole_batch(m, s)); }
+        for (int i = 0; i < 3; ++i) { WMCHK(dec_linear_dispatch(T, p, st)); if (!wm_env("WM_STAMP_NO_STREAM")) WMCHK(launch_cross_attn(m, s, i, whole_batch(m, s))); }
         p.dbg = dbg.as<long long>();
         HIPCHK(hipEventRecord(e0, st));
-        dec_linear_dispatch(T, p, st);
+        WMCHK(dec_linear_dispatch(T, p, st));
         HIPCHK(hipEventRecord(e1, st));
         HIPCHK(hipEventSynchronize(e1));
         std::vector<long long> h((size_t)4096 * 16 * 8);
@@ -1833,12 +1859,12 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
         p.A = s->xn.p; p.W = w0.qkv_w.p; p.C = s->qkv.p; p.M = M; p.N = 3 * c.d_model; p.K = c.d_model;
         p.lda = c.d_model; p.ldw = c.d_model; p.ldc = 3 * c.d_model; p.bias = w0.qkv_b.as<float>();
         if (!gemm_nt_fuses_layernorm(T == WM_F32 ? 4 : 2, p, 1)) return fail(WM_E_ARG, "this configuration does not run the row-panel kernel");
-        for (int i = 0; i < 3; ++i) gemm_dispatch(T, T, p, 1, st);
+        for (int i = 0; i < 3; ++i) WMCHK(gemm_dispatch(T, T, p, 1, st));
         DevBuf dbg;
         WMCHK(dbg.alloc((size_t)512 * 96 * 8, true));
         p.dbg = dbg.as<long long>();
         HIPCHK(hipEventRecord(e0, st));
-        gemm_dispatch(T, T, p, 1, st);
+        WMCHK(gemm_dispatch(T, T, p, 1, st));
         HIPCHK(hipEventRecord(e1, st));
         HIPCHK(hipEventSynchronize(e1));
         std::vector<long long> h((size_t)512 * 96);
@@ -1875,10 +1901,10 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
         p.x = s->dx.as<float>(); p.ldx = c.d_model; p.ln_g = m->dec_ln_g.as<float>(); p.ln_b = m->dec_ln_b.as<float>();
         p.W = T == WM_F32 ? m->tok_emb_f.p : m->tok_emb_t.p; p.N = c.vocab; p.K = c.d_model; p.B = s->B; p.ldo = m->Vpad;
         p.amax_val = s->amax_val.as<float>(); p.amax_idx = s->amax_idx.as<int>(); p.amax_stride = s->npart;
-        for (int i = 0; i < 3; ++i) { DISPATCH_DT(T, TT, launch_dec_logits<TT>(p, st)); launch_cross_attn(m, s, i, whole_batch(m, s)); }
+        for (int i = 0; i < 3; ++i) { DISPATCH_DT(T, TT, (void)launch_dec_logits<TT>(p, st)); WMCHK(launch_cross_attn(m, s, i, whole_batch(m, s))); }
         p.dbg = dbg.as<long long>();
         HIPCHK(hipEventRecord(e0, st));
-        DISPATCH_DT(T, TT, launch_dec_logits<TT>(p, st));
+        DISPATCH_DT(T, TT, (void)launch_dec_logits<TT>(p, st));
         HIPCHK(hipEventRecord(e1, st));
         HIPCHK(hipEventSynchronize(e1));
         std::vector<long long> h((size_t)nwg * 64);
@@ -1958,7 +1984,7 @@ extern "C" int wm_op_matmul_nt(float* C, const float* A, const float* Bm, const 
         p.ldw = K;
         p.ldc = N;
         p.bias = bias ? b.as<float>() : nullptr;
-        gemm_dispatch(dtype, WM_F32, p, 1, st);
+        WMCHK(gemm_dispatch(dtype, WM_F32, p, 1, st));
         HIPCHK(hipMemcpy(C, c.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     } else {  // skinny path: the decode-step linear kernel
         const int Np = (N + 15) / 16 * 16;
@@ -1991,7 +2017,7 @@ extern "C" int wm_op_matmul_nt(float* C, const float* A, const float* Bm, const 
         p.bias = bias ? b.as<float>() : nullptr;
         p.out = c.as<float>();
         p.ldo = Np;
-        dec_linear_dispatch(dtype, p, st);
+        WMCHK(dec_linear_dispatch(dtype, p, st));
         HIPCHK(hipMemcpy2D(C, (size_t)N * 4, c.p, (size_t)Np * 4, (size_t)N * 4, M, hipMemcpyDeviceToHost));
     }
     HIPCHK(hipGetLastError());
@@ -2056,7 +2082,7 @@ extern "C" int wm_op_mlp_block(float* x, const float* ln_g, const float* ln_b, c
     f1.bias = bb1.as<float>();
     f1.act = 1;
     f1.gelu_mode = gelu_mode;
-    ln_then_gemm(dtype, dtype, f1, dx.as<float>(), g1.as<float>(), b1.as<float>(), st);
+    WMCHK(ln_then_gemm(dtype, dtype, f1, dx.as<float>(), g1.as<float>(), b1.as<float>(), st));
     GemmParams f2{};
     f2.A = hid.p;
     f2.W = w2.p;
@@ -2077,7 +2103,7 @@ extern "C" int wm_op_mlp_block(float* x, const float* ln_g, const float* ln_b, c
         f2.lno_out = xn.p;
         fused_next = true;
     }
-    gemm_dispatch(dtype, WM_F32, f2, 1, st);
+    WMCHK(gemm_dispatch(dtype, WM_F32, f2, 1, st));
     if (want_next && !fused_next)
         DISPATCH_DT(dtype, TT, launch_layernorm_rows<TT>(dx.as<float>(), g2.as<float>(), b2.as<float>(), xn.p, nullptr, M, d, 1e-5f, st));
     HIPCHK(hipGetLastError());
@@ -2164,7 +2190,7 @@ extern "C" int wm_op_attention_cached(float* out, const float* q, const float* k
         a.nsplit = n_chunks;
         a.part_o = po.as<float>();
         a.part_ml = pml.as<float>();
-        attn_decode_dispatch(kv_dtype, a, nullptr);
+        WMCHK(attn_decode_dispatch(kv_dtype, a, nullptr));
         launch_attn_combine(po.as<float>(), pml.as<float>(), o.p, WM_F32, B, n_chunks, n_heads, (int)d, nullptr);
     } else {
         StepCtl h{};
@@ -2176,7 +2202,7 @@ extern "C" int wm_op_attention_cached(float* out, const float* q, const float* k
         a.nsplit = 1;
         a.direct_out = o.as<float>();
         a.out_dtype = WM_F32;
-        attn_decode_dispatch(kv_dtype, a, nullptr);
+        WMCHK(attn_decode_dispatch(kv_dtype, a, nullptr));
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(out, o.p, (size_t)B * d * 4, hipMemcpyDeviceToHost));
@@ -2247,7 +2273,7 @@ extern "C" int wm_op_conv1d_k3(float* out, const float* inp, const float* weight
     p.ldw = 3 * Cp;
     p.ldc = C_out;
     p.bias = b.as<float>();
-    gemm_dispatch(dtype, WM_F32, p, 1, nullptr);
+    WMCHK(gemm_dispatch(dtype, WM_F32, p, 1, nullptr));
     if (out_T) {
         HIPCHK(hipMemcpy(out, o.p, (size_t)L_out * C_out * 4, hipMemcpyDeviceToHost));
     } else {

@@ -16,19 +16,32 @@ static constexpr const char* wm_env(const char*) { return nullptr; }
 
 namespace wm {
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: remember it per device (the C-ABI
-// takes a device index; two models on two GPUs in one process both need it).  Returns the HIP status.
-template <typename F> static inline hipError_t ensure_dyn_lds(F* kernel, int bytes) {
-    static std::atomic<unsigned long long> done{0};  // one flag bit per device, per kernel instantiation
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of ONE kernel: the record is keyed on the kernel itself
+// (a non-type template parameter — keyed on the function TYPE, every instantiation of a kernel template with the same signature
+// shared one flag) and holds, per device, the largest byte count set so far.  Returns the HIP status.
+template <auto Kernel> static inline hipError_t ensure_dyn_lds(int bytes) {
+    static std::atomic<int> set_bytes[64];  // zero-initialised; index = device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    std::atomic<int>& have = set_bytes[dev & 63];
+    if (have.load(std::memory_order_acquire) >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) {
+        int cur = have.load(std::memory_order_relaxed);
+        while (cur < bytes && !have.compare_exchange_weak(cur, bytes, std::memory_order_release)) {
+        }
+    }
     return e;
 }
+
+// Launcher status: a launcher that cannot serve a shape REFUSES it (nothing is launched) and says so; the C-ABI entry above turns
+// that into WM_E_ARG with wm_last_error set.  0 = launched.
+enum { WM_LAUNCH_OK = 0, WM_LAUNCH_BAD_SHAPE = 1, WM_LAUNCH_HIP = 2 };
+// message of the last refusal on this thread (static text)
+const char* launch_last_refusal();
+int launch_refuse(const char* why);  // records `why`, returns WM_LAUNCH_BAD_SHAPE
+int launch_hip_failed(const char* what, hipError_t e);
 
 // Per-state decode control block, resident in HBM so that a captured decode step can be replayed unchanged.
 struct StepCtl {
@@ -69,7 +82,7 @@ bool gemm_nt_fuses_layernorm_out(int operand_bytes, const GemmParams& p);
 // true when launch_gemm_nt<T, *> takes the A-stationary row-panel kernel for these parameters (the only one that can fuse a LayerNorm)
 bool gemm_nt_fuses_layernorm(int operand_bytes, const GemmParams& p, int batch);
 template <typename T> void launch_mel_transpose_pad(const float* mel, void* out, int B, int C, int L, int Cp, hipStream_t st);
-template <typename T, typename TO> void launch_gemm_nt(const GemmParams& p, int batch, hipStream_t st);
+template <typename T, typename TO> int launch_gemm_nt(const GemmParams& p, int batch, hipStream_t st);  // WM_LAUNCH_*
 template <typename T>
 void launch_layernorm_rows(const float* x, const float* gamma, const float* beta, void* out_t, float* out_f, int rows,
                            int cols, float eps, hipStream_t st);
@@ -156,9 +169,9 @@ struct DecLinearParams {
     int ts_id;
     long long* dbg;  // developer build: per-(workgroup, wave) phase stamps of dec_logits (100 MHz clock), null = off
 };
-template <typename TW> void launch_dec_linear(const DecLinearParams& p, hipStream_t st);
+template <typename TW> int launch_dec_linear(const DecLinearParams& p, hipStream_t st);  // WM_LAUNCH_*
 bool dec_linear_supports_k(int K);  // K/32 k-steps must split into NW <= 16 waves x KPW <= 4 steps (checked at model load)
-template <typename TW> void launch_dec_logits(const DecLinearParams& p, hipStream_t st);
+template <typename TW> int launch_dec_logits(const DecLinearParams& p, hipStream_t st);  // WM_LAUNCH_*
 int dec_logits_parts(int N);  // fused-argmax partials per utterance that launch_dec_logits writes (amax_stride must cover them)
 int dec_logits_ids_per_part(int N);  // vocabulary ids one part covers
 
@@ -188,7 +201,7 @@ struct AttnDecParams {
     long long* ts;  // developer timeline (null = off): see ts_put in kernels_decoder.hip
     int ts_id;
 };
-template <typename TKV> void launch_attn_decode(const AttnDecParams& p, hipStream_t st);
+template <typename TKV> int launch_attn_decode(const AttnDecParams& p, hipStream_t st);  // WM_LAUNCH_*
 void launch_attn_combine(const float* part_o, const float* part_ml, void* out, int out_dtype, int B, int nsplit, int H, int d,
                          hipStream_t st, long long* ts = nullptr, int ts_id = 0);
 
