@@ -153,6 +153,13 @@ int wm_transcribe_pcm(wm_model* m, const float* pcm, const int32_t* n_samples, i
 /* matmul(C, A, B, bias)  whisper_tensor.mojo:151-246 : C[M,N] = A[M,K]·B[N,K]ᵀ (+bias[N], may be NULL).
  * dtype selects the operand rounding (WM_F32 exact).  Requires K % 32 == 0. */
 int wm_op_matmul_nt(float* C, const float* A, const float* B, const float* bias, int M, int N, int K, int dtype);
+/* C = layer_norm(A, ln_g, ln_b, 1e-5) · Bᵀ (+ bias): the LayerNorm -> projection pair of ResidualAttentionBlock.forward
+ * (layers.mojo:449-455, 489-497) on the encoder's kernels.  require_fused != 0 demands the one-kernel form (the LayerNorm applied while
+ * the GEMM loads its fp32 A rows; 16-bit dtypes, K = 384, N % 128 == 0, N <= 3072): any other shape is REFUSED by the kernel launcher —
+ * WM_E_ARG, wm_last_error says why, nothing is launched and C is untouched.  require_fused == 0: fused where possible, else a
+ * LayerNorm launch + a plain GEMM.  N % 128 == 0, K % 128 == 0, K <= 1024.  Known-answer and negative tests. */
+int wm_op_ln_matmul_nt(float* C, const float* A, const float* ln_g, const float* ln_b, const float* B, const float* bias, int M, int N,
+                       int K, int dtype, int require_fused);
 /* layer_norm(out, inp, gamma, beta, eps)  whisper_tensor.mojo:249-285 (one-pass variance). cols % 128 == 0, <= 1024 */
 int wm_op_layer_norm(float* out, const float* inp, const float* gamma, const float* beta, int rows, int cols,
                      float eps);

@@ -7,6 +7,8 @@ Bars (the path is IEEE fp32 except token ids / argmax indices):
   * fp32 mode: encoder rows and logits within 5e-5 abs of the oracle (values are O(1); different reduction order);
   * bf16 / f16 operand modes: within 16-bit tolerances written next to each test.
 Nothing here reads /root/reference."""
+import os
+
 import numpy as np
 import pytest
 
@@ -603,3 +605,75 @@ def test_full_size_properties_b64(hip, tiny_cfg, tiny_weights):
     assert all(len(t) == 45 and t[:4] == [50258, 50259, 50359, 50363] and max(t) < 51865 and min(t) >= 0 for t in a)
     for i in (0, 17, 63):
         assert m.transcribe_batch(mels[i], max_loop=40, ignore_eot=True)[0] == a[i]
+
+
+@pytest.mark.skipif(not os.environ.get("WHISPER_REAL_DIR"), reason="real whisper_tiny_weights.bin + sample_input.bin are "
+                    "git-ignored upstream and need network to create; set WHISPER_REAL_DIR to a dir holding them")
+@pytest.mark.parametrize("mode", ["ref", "hf"])
+def test_real_weights_expected_tokens_hip(hip, tiny_cfg, mode):
+    """The reference's one golden (expected_tokens.txt, main.mojo:23-37) on the HIP path — the twin of
+    tests/test_oracle_golden.py::test_real_weights_expected_tokens: Whisper.load(whisper_tiny_weights.bin),
+    Whisper.transcribe(sample_input.bin) in fp32, in the reference's semantics (tanh GELU, positions current_len - 1) and in
+    HF's (erf GELU, positions current_len — the model that WROTE the golden, export_weights.py:125-131); tokens[4:-1] must be
+    the 89 ids.  README claims the reference reproduces them (readme.md:19); HF mode must by construction."""
+    import re
+    from whisper_mojo_amd.loader import WeightLoader
+    from whisper_mojo_amd.whisper import Whisper
+    d = os.environ["WHISPER_REAL_DIR"]
+    ids = [int(x) for x in re.findall(r"\((\d+)\)", open(os.path.join(os.path.dirname(__file__), "golden", "expected_tokens.txt")).read())]
+    mel = np.fromfile(os.path.join(d, "sample_input.bin"), np.float32).reshape(80, 3000)
+    m = Whisper(tiny_cfg, gelu_mode=0 if mode == "ref" else 1, pos_mode=0 if mode == "ref" else 1, max_batch=1)
+    m.load(WeightLoader(os.path.join(d, "whisper_tiny_weights.bin")))
+    toks = m.transcribe(mel)
+    assert toks[:4] == [50258, 50259, 50359, 50363] and toks[-1] == 50257
+    assert toks[4:-1] == ids
+
+
+def test_ln_matmul_fused_and_refused_shapes(hip):
+    """The LayerNorm -> projection pair (layers.mojo:449-455) through wm_op_ln_matmul_nt.  (1) K = 384 with 16-bit operands: the
+    one-kernel form (LayerNorm in the row-panel GEMM's A load) equals float64 on the operands it rounds, and the unfused form.
+    (2) Shapes the fused kernel does not take — K = 256, fp32 operands, N = 3200 — asked for WITH require_fused are REFUSED by the
+    launcher: the C-ABI returns WM_E_ARG with a message, launches nothing, and the output buffer keeps its contents (round 2's
+    launchers printed to stderr and returned WM_OK with stale output)."""
+    from whisper_mojo_amd import _lib, whisper_tensor as wt
+    rng = np.random.default_rng(11)
+
+    def case(M, N, K):
+        A = (rng.standard_normal((M, K)) * 1.5 + 0.3).astype(np.float32)
+        g = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+        b = (0.1 * rng.standard_normal(K)).astype(np.float32)
+        W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+        bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+        return A, g, b, W, bias
+
+    def bf16_round(x):
+        u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+        return u.astype(np.uint32).view(np.float32)
+
+    A, g, b, W, bias = case(300, 768, 384)
+    mean = A.mean(1, keepdims=True, dtype=np.float64)
+    var = (A.astype(np.float64) ** 2).mean(1, keepdims=True) - mean ** 2
+    xn = ((A - mean) / np.sqrt(var + 1e-5) * g + b).astype(np.float32)
+    want = bf16_round(xn).astype(np.float64) @ bf16_round(W).astype(np.float64).T + bias
+    fused = np.full((300, 768), 7.0, np.float32)
+    wt.ln_matmul(fused, A, g, b, W, bias, dtype=1, require_fused=True)
+    plain = np.empty_like(fused)
+    wt.ln_matmul(plain, A, g, b, W, bias, dtype=1)
+    # the LayerNorm itself is fp32 (vs float64 here): a bf16 ulp of an operand flips now and then -> a few 1e-3 on O(1) sums
+    assert np.abs(fused - want).max() < 2e-2 and np.abs(plain - want).max() < 2e-2
+    assert np.abs(fused - plain).max() < 2e-2
+    for (M, N, K, dt, why) in ((64, 256, 256, 1, "K = 256"), (64, 256, 384, 0, "fp32 operands"), (64, 3200, 384, 1, "N > 3072")):
+        A, g, b, W, bias = case(M, N, K)
+        out = np.full((M, N), 7.0, np.float32)
+        with pytest.raises(_lib.WhisperMiError, match="LayerNorm fused into the A load") as ei:
+            wt.ln_matmul(out, A, g, b, W, bias, dtype=dt, require_fused=True)
+        assert "-1" in str(ei.value).split(":")[0], why  # WM_E_ARG
+        assert np.all(out == 7.0), why                    # nothing was written
+        wt.ln_matmul(out, A, g, b, W, bias, dtype=dt)     # the same shape without the demand: served by LayerNorm + plain GEMM
+        assert np.all(out != 7.0)
+    # the skinny path: a K the decode kernel cannot split over its waves is refused, not truncated
+    out = np.full((2, 10), 7.0, np.float32)
+    with pytest.raises(_lib.WhisperMiError, match="K too large"):
+        wt.matmul(out, rng.standard_normal((2, 4096)).astype(np.float32), rng.standard_normal((10, 4096)).astype(np.float32))
+    assert np.all(out == 7.0)

@@ -53,6 +53,55 @@ def test_tiny(tiny_cfg, tiny_weights, mode):
     _check(tiny_cfg, tiny_weights, "tiny", mode)
 
 
+# ---- long / wide pins (round 3, tools/make_golden.py long): the ranges the GPU parity tests lean on ---------------------------------
+LONG = ["tiny_ref_s1000_195", "tiny_ref_s1001_195", "tiny_ref_s1017_195", "tiny_hf_s1002_195", "tiny_ref_s1005_edge444",
+        "base_ref_s1000_40", "base_hf_s1003_40"]
+TIE = 1e-4  # a free-running greedy stream may part from the fixture's only where the fixture's own top1-top2 margin is below this
+
+
+@pytest.fixture(scope="module")
+def base_weights():
+    from whisper_mojo_amd import WhisperConfig
+    return oracle.synth_weights_c(WhisperConfig.base(), 0)
+
+
+@pytest.mark.parametrize("name", LONG)
+def test_long_pin(name, tiny_cfg, tiny_weights, base_weights):
+    """The oracle against the HF architecture on the same synthetic weights at the lengths, seeds and dims the -m gpu tests trust it
+    for: the reference's full 195 loop iterations (whisper.mojo:205) for three mel seeds, the 448-row context edge (whisper.mojo:193:
+    444 fed-back ids), and Whisper-base dims (d = 512, 8 heads, 6 + 6 layers).  At EVERY position, along the fixture's own greedy
+    stream: the top-8 logits, the first 16 logits (<= 2e-5) and the row sum; ids exact wherever the margin exceeds 1e-4; and the
+    oracle's free-running greedy loop reproduces the stream (up to a near-tie, if the fixture has one)."""
+    from whisper_mojo_amd import WhisperConfig
+    g = golden("long_" + name)
+    mode = str(g["mode"])
+    gm, pm = MODES[mode]
+    dims = [int(x) for x in g["dims"]]
+    cfg = WhisperConfig(dims[0], dims[1], dims[2], dims[7], dims[3], dims[4], dims[5], dims[6])
+    base = dims[0] == 512
+    weights = base_weights if base else tiny_weights
+    mel = synth.synth_mel(cfg, int(g["mel_seed"]))
+    M = oracle.OracleModel(cfg, weights, gelu_mode=gm)
+    enc = M.encode(mel)
+    assert np.abs(enc.astype(np.float64).sum(1) - g["enc_out_rowsum"]).max() < 3e-4
+    toks = g["greedy_tokens"]
+    steps = len(toks) - 5
+    assert list(toks[:4]) == [50258, 50259, 50359, 50363] and steps == {"195": 195, "edge444": 444, "40": 39}[name.split("_")[-1]]
+    fl = M.teacher_forced(enc, toks[:-1], 4, pm)  # logits of every position along the fixture's stream
+    assert fl.shape[0] == steps + 1
+    assert np.abs(np.take_along_axis(fl, g["top_idx"], 1) - g["top_val"]).max() < TOL
+    assert np.abs(fl[:, :16] - g["logit_head"]).max() < TOL
+    assert np.abs(fl.astype(np.float64).sum(1) - g["logit_sum"]).max() < 0.05
+    margins = g["top_val"][:, 0] - g["top_val"][:, 1]
+    clear = margins > TIE
+    assert clear.sum() >= len(margins) - 3
+    assert np.array_equal(fl.argmax(1)[clear], toks[4:][clear])
+    got = M.transcribe(enc_out=enc, prompt=toks[:4], max_loop=steps, pos_mode=pm, ignore_eot=True)
+    assert len(got) == len(toks)
+    diff = np.nonzero(np.asarray(got) != toks)[0]
+    assert diff.size == 0 or margins[diff[0] - 4] < TIE, (diff[:3], margins[diff[0] - 4])
+
+
 def test_modes_are_distinguishable(micro_cfg, micro_weights):
     """REF-mode oracle must NOT match the HF-mode golden: the two quirks are observable."""
     g = golden("micro_hf")

@@ -15,6 +15,11 @@ its outputs in two modes:
 
 No logit processors are applied in either mode (whisper.mojo:198,219 use a raw argmax).
 Usage: python tools/make_golden.py            # writes tests/golden/{micro,tiny}_{hf,ref}.npz
+       python tools/make_golden.py long       # writes the long / wide pins (round 3): tests/golden/long_*.npz —
+                                              #   tiny, REF mode, mel seeds 1000 / 1001 / 1017, the reference's full 195 loop iterations
+                                              #   (whisper.mojo:205); tiny, seed 1005, 444 iterations = the 448-row context edge
+                                              #   (whisper.mojo:193); tiny HF mode 195 iterations; Whisper-base dims (d = 512, 8 heads,
+                                              #   6 + 6 layers), 40 positions.  Top-8 logits + row sums per position: a few KB each.
 """
 import os
 import sys
@@ -175,9 +180,41 @@ def make(cfg_name: str, cfg: WhisperConfig, ref_mode: bool, steps: int, full: bo
           float((gv[:, 0] - gv[:, 1]).min()))
 
 
+@torch.no_grad()
+def make_long(name: str, cfg: WhisperConfig, ref_mode: bool, mel_seed: int, steps: int):
+    """Free-running greedy decode of `steps` loop iterations (1 prefill + steps single-token forwards): the ids, and per position
+    the top-8 logits, the row sum and the first 16 logits.  Pins the oracle at cache lengths the GPU parity tests lean on."""
+    flat = synth.synth_weights(cfg, 0)
+    w = synth.split_weights(cfg, flat)
+    mel = synth.synth_mel(cfg, mel_seed)
+    m = hf_model(cfg, w, ref_mode)
+    with TanhStemGelu(ref_mode):
+        enc_out = m.model.encoder(torch.from_numpy(mel)[None]).last_hidden_state
+    toks, logits = run_decoder(m, enc_out, np.asarray(PROMPT, np.int32), 4, ref_mode, greedy_steps=steps)
+    ti, tv = topk(logits)
+    eo = enc_out[0].numpy()
+    out = dict(mode=np.array("ref" if ref_mode else "hf"), weight_seed=np.int64(0), mel_seed=np.int64(mel_seed),
+               dims=np.asarray([cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.ffn, cfg.n_mels, cfg.n_audio_ctx, cfg.n_text_ctx, cfg.vocab_size], np.int32),
+               prompt=np.asarray(PROMPT, np.int32), greedy_tokens=toks, top_idx=ti, top_val=tv,
+               logit_sum=logits.astype(np.float64).sum(1), logit_head=logits[:, :16].copy(),
+               enc_out_rowsum=eo.astype(np.float64).sum(1))
+    path = os.path.join(ROOT, "tests", "golden", f"long_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes;", len(toks), "ids; min top1-top2 margin", float((tv[:, 0] - tv[:, 1]).min()), flush=True)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "long":
+        tiny = WhisperConfig.tiny()
+        for seed in (1000, 1001, 1017):
+            make_long(f"tiny_ref_s{seed}_195", tiny, True, seed, 195)
+        make_long("tiny_hf_s1002_195", tiny, False, 1002, 195)
+        make_long("tiny_ref_s1005_edge444", tiny, True, 1005, tiny.n_text_ctx - 4)
+        make_long("base_ref_s1000_40", WhisperConfig.base(), True, 1000, 39)
+        make_long("base_hf_s1003_40", WhisperConfig.base(), False, 1003, 39)
+        sys.exit(0)
     for ref_mode in (False, True):
         make("micro", WhisperConfig.micro(), ref_mode, steps=24, full=True)
         make("tiny", WhisperConfig.tiny(), ref_mode, steps=24, full=False)

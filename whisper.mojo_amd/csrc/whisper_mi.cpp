@@ -2024,6 +2024,52 @@ extern "C" int wm_op_matmul_nt(float* C, const float* A, const float* Bm, const 
     return 0;
 }
 
+// C = layer_norm(A, ln_g, ln_b) · Bᵀ (+ bias): the LN -> projection pair of ResidualAttentionBlock.forward (layers.mojo:449-455,
+// 489-497) on the encoder's kernels.  require_fused != 0 demands the ONE-kernel form (LayerNorm applied while the row-panel GEMM
+// loads its fp32 A rows): a shape that kernel does not take is refused by the launcher — WM_E_ARG, nothing launched, C untouched.
+extern "C" int wm_op_ln_matmul_nt(float* C, const float* A, const float* ln_g, const float* ln_b, const float* Bm, const float* bias,
+                                  int M, int N, int K, int dtype, int require_fused) {
+    if (!C || !A || !ln_g || !ln_b || !Bm || M <= 0 || N <= 0 || K <= 0) return fail(WM_E_ARG, "bad argument");
+    if (dtype < 0 || dtype > 2) return fail(WM_E_ARG, "bad dtype");
+    if (K % 128 || K > 1024) return fail(WM_E_ARG, "K must be a multiple of 128 and <= 1024 (layer_norm rows)");
+    TmpDev t;
+    t.bufs.reserve(8);
+    hipStream_t st = nullptr;
+    const size_t Mp = ((size_t)M + 127) / 128 * 128;
+    std::vector<float> Ap(Mp * K, 0.f);
+    memcpy(Ap.data(), A, (size_t)M * K * 4);
+    DevBuf &x = t.add(), &xn = t.add(), &w = t.add(), &c = t.add(), &b = t.add(), &g = t.add(), &be = t.add();
+    WMCHK(upload(x, Ap.data(), Ap.size(), WM_F32));
+    WMCHK(xn.alloc(Mp * K * dt_size(dtype), true));
+    WMCHK(upload(w, Bm, (size_t)N * K, dtype));
+    WMCHK(c.alloc((size_t)M * N * 4));
+    WMCHK(upload(g, ln_g, K, WM_F32));
+    WMCHK(upload(be, ln_b, K, WM_F32));
+    if (bias) WMCHK(upload(b, bias, N, WM_F32));
+    GemmParams p{};
+    p.A = xn.p;
+    p.W = w.p;
+    p.C = c.p;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.lda = K;
+    p.ldw = K;
+    p.ldc = N;
+    p.bias = bias ? b.as<float>() : nullptr;
+    if (require_fused) {  // handed to the launcher as asked: it either fuses or refuses
+        p.A = x.p;
+        p.ln_g = g.as<float>();
+        p.ln_b = be.as<float>();
+        WMCHK(gemm_dispatch(dtype, WM_F32, p, 1, st));
+    } else {
+        WMCHK(ln_then_gemm(dtype, WM_F32, p, x.as<float>(), g.as<float>(), be.as<float>(), st));
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(C, c.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int wm_op_layer_norm(float* out, const float* inp, const float* gamma, const float* beta, int rows, int cols, float eps) {
     if (!out || !inp || !gamma || !beta || rows <= 0 || cols <= 0) return fail(WM_E_ARG, "bad argument");
     if (cols % 128 || cols > 1024) return fail(WM_E_ARG, "cols must be a multiple of 128 and <= 1024");

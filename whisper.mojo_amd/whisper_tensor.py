@@ -35,6 +35,18 @@ def matmul(C_out: np.ndarray, A, B, bias=None, dtype=DT_F32):
     _lib.check(_lib.lib().wm_op_matmul_nt(_fp(C_out), _fp(A), _fp(B), _fp(b), M, N, K, dtype))
 
 
+def ln_matmul(C_out: np.ndarray, A, ln_g, ln_b, B, bias=None, dtype=DT_F32, require_fused: bool = False):
+    """layers.mojo:449-455 / 489-497: C = layer_norm(A)·Bᵀ (+bias).  require_fused: demand the one-kernel form (the LayerNorm applied
+    while the GEMM loads A); a shape that kernel does not take raises (WM_E_ARG) and leaves C_out untouched."""
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    A, B, ln_g, ln_b = f(A), f(B), f(ln_g).ravel(), f(ln_b).ravel()
+    b = None if bias is None or bias.size == 0 else f(bias).ravel()
+    M, K = A.shape
+    N = B.shape[0]
+    _chk_out(C_out, (M, N))
+    _lib.check(_lib.lib().wm_op_ln_matmul_nt(_fp(C_out), _fp(A), _fp(ln_g), _fp(ln_b), _fp(B), _fp(b), M, N, K, dtype, int(require_fused)))
+
+
 def mlp_block(x: np.ndarray, ln_g, ln_b, fc1_w, fc1_b, fc2_w, fc2_b, next_ln=None, dtype=DT_F32, gelu_mode: int = GELU_TANH):
     """layers.mojo:489-517 (the MLP half of ResidualAttentionBlock.forward): x += fc2(gelu(fc1(layer_norm(x)))), in place.
     next_ln = (gamma, beta): also returns layer_norm(x_new) rounded to the operand dtype — the rows the next projection reads."""
