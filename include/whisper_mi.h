@@ -123,20 +123,28 @@ int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, int q_len, c
 /* ---- Whisper.transcribe(mel) -> List[Int]   whisper.mojo:184-223 ------------------------------------------
  * tokens_out: host [B, n_prompt + 1 + max_loop]; row b holds prompt + generated ids (incl. the trailing eot when
  * hit), exactly the reference's list; n_tokens[b] = its length.  The whole greedy loop runs on the GPU (token
- * feedback never visits the host); the host only polls "all finished" every few steps. */
+ * feedback never visits the host); the host only reads a device-written "utterances finished" word between sub-chunks of 8 steps
+ * and stops enqueueing once every utterance has emitted eot (see wm_transcribe_submit). */
 int wm_transcribe(wm_model* m, const float* mel, int mel_on_device, int B, const wm_decode_opts* opts,
                   int32_t* tokens_out, int32_t* n_tokens);
 
-/* Pipelined form for back-to-back batches (serving / bench): wm_transcribe_submit enqueues the encoder, the
- * prompt prefill and the whole greedy loop on the slot's own HIP stream and returns immediately; wm_transcribe_wait blocks until that slot's
- * ids are ready and copies them out (same layout as wm_transcribe).  Eight slots (0..7): submitting batch i+1 before
- * waiting for batch i overlaps its MFMA-bound encoder with batch i's latency/HBM-bound decode; four passes in flight is
- * the measured optimum (the chip runs four hardware queues at a time, and ROCm must be allowed that many per-process
- * queues: GPU_MAX_HW_QUEUES >= 8 in the environment before HIP initialises — see INTEGRATION.md).  In this form every
- * max_loop step is enqueued (no early exit); finished utterances simply stop recording, so the ids are identical to
- * wm_transcribe's.  mel must stay valid until the matching wait when it is a device pointer. */
+/* Pipelined form for back-to-back batches (serving / bench): wm_transcribe_submit enqueues the encoder, the prompt prefill and
+ * the greedy loop on the slot's own HIP stream and returns immediately; wm_transcribe_wait blocks until that slot's ids are
+ * ready and copies them out (same layout as wm_transcribe).  Eight slots (0..7): submitting batch i+1 before waiting for batch i
+ * overlaps its MFMA-bound encoder with batch i's latency/HBM-bound decode; four passes in flight is the measured optimum (the chip
+ * runs four hardware queues at a time, and ROCm must be allowed that many per-process queues: GPU_MAX_HW_QUEUES >= 8 in the
+ * environment before HIP initialises — see INTEGRATION.md).
+ * The loop stops like the reference's (whisper.mojo:206-207: break at eot — here: once EVERY utterance of the batch has emitted
+ * eot): with ignore_eot == 0 it is enqueued in sub-chunks of 8 steps, two sub-chunks ahead of the GPU, by a host thread of the
+ * library that reads a device-written "utterances finished" word between sub-chunks (no stream synchronisation); it therefore runs
+ * at most 16 steps (+ the sub-chunk in progress) past the longest utterance, and the ids are identical to wm_transcribe's.  With
+ * ignore_eot != 0 ("fixed" mode) all max_loop steps are enqueued at submit.  mel must stay valid until the matching wait when it
+ * is a device pointer. */
 int wm_transcribe_submit(wm_model* m, int slot, const float* mel, int mel_on_device, int B, const wm_decode_opts* opts);
 int wm_transcribe_wait(wm_model* m, int slot, int32_t* tokens_out, int32_t* n_tokens);
+/* Loop iterations that were enqueued for the slot's most recent completed pass (slot 0 also serves wm_transcribe): max_loop when
+ * the pass ran to its bound, less when the early exit cut it.  -1: no pass yet / bad slot.  Diagnostics and tests. */
+int wm_transcribe_steps(wm_model* m, int slot);
 
 /* ---- log-mel front end --------------------------------------------------------------------------
  * Replaces the reference's call to HF WhisperProcessor (export_weights.py:100-116): 16 kHz mono PCM -> pad / trim to the

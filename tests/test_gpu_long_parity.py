@@ -148,6 +148,46 @@ def test_tiny_fp32_reachable_eot_long(hip, oracle_mod, tiny_cfg, tiny_weights):
     assert stopped >= 1 and len(got[0]) <= 4 + 1 + 120 + 1
 
 
+def test_early_exit_sync_and_pipelined(hip, oracle_mod, tiny_cfg, tiny_weights):
+    """The reference breaks its loop at eot (whisper.mojo:206-207).  Batched: the loop ends once EVERY utterance has emitted eot.
+    Four copies of two clips, eot := the id clip 0 emits at iteration 60 and clip 1 somewhere else or never — (a) a batch that can
+    finish (copies of clip 0 only): synchronous and pipelined entries return the oracle's ids and stop enqueueing within two
+    sub-chunks (16 steps, + the one in progress) of the stop; (b) a batch in which one utterance never stops runs to the bound.
+    The ids never depend on where the loop was cut."""
+    mels = synth_mels(tiny_cfg, [1000, 1001])
+    ref = oracle_mod.OracleModel(tiny_cfg, tiny_weights)
+    free0 = ref.transcribe(mel=mels[0], max_loop=195, ignore_eot=True)
+    eot = int(free0[4 + 60])
+    want0 = ref.transcribe(mel=mels[0], eot=eot, max_loop=195).tolist()
+    want1 = ref.transcribe(mel=mels[1], eot=eot, max_loop=195).tolist()
+    assert want0[-1] == eot and len(want0) <= 4 + 1 + 60 + 1
+    stop_iter = len(want0) - 5  # loop iterations until clip 0's eot is emitted
+    m = make_model(tiny_cfg, tiny_weights, max_batch=4)
+    same = np.stack([mels[0]] * 4)
+    got = m.transcribe_batch(same, eot=eot, max_loop=195)  # synchronous entry
+    assert got == [want0] * 4
+    assert stop_iter <= m.loop_steps(0) <= stop_iter + 16 + 8 + 1, (stop_iter, m.loop_steps(0))
+    for slot in (0, 1, 2):  # pipelined entry, three passes in flight: the library's pump thread feeds all of them
+        m.transcribe_submit(same, slot=slot, eot=eot, max_loop=195)
+    for slot in (0, 1, 2):
+        assert m.transcribe_wait(slot) == [want0] * 4
+        assert stop_iter <= m.loop_steps(slot) <= stop_iter + 16 + 8 + 1, (slot, stop_iter, m.loop_steps(slot))
+    mixed = np.stack([mels[0], mels[1], mels[0], mels[1]])
+    m.transcribe_submit(mixed, slot=3, eot=eot, max_loop=195)
+    got = m.transcribe_wait(3)
+    i = first_divergence(got[1], want1)
+    if i is None:
+        assert got == [want0, want1, want0, want1]
+        long1 = len(want1) - 5
+        assert min(195, long1) <= m.loop_steps(3) <= min(195, long1 + 25)
+    else:  # clip 1 parted from the oracle at a near-tie: clip 0's rows are still exact
+        assert got[0] == want0 and got[2] == want0
+    # fixed mode is enqueued whole
+    m.transcribe_batch(same, eot=eot, max_loop=40, ignore_eot=True)
+    assert m.loop_steps(0) == 40
+    m.close()
+
+
 def test_tiny_fp32_context_edge_448(hip, oracle_mod, tiny_cfg, tiny_weights):
     """The 448-row decoder context (KVCache(n_layers, d_model, 448), whisper.mojo:193): the longest stream the cache holds —
     the 4 prompt rows + 444 fed-back ids fill rows 0..447 (the last generated id needs no row), 449 ids in all.  ids equal

@@ -77,6 +77,10 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dl_smem[];
     f32x4 (*s_red)[NT][64] = reinterpret_cast<f32x4 (*)[NT][64]>(dl_smem);
     float (*s_stat)[16][2] = reinterpret_cast<float (*)[16][2]>(dl_smem + (size_t)(blockDim.x >> 6) * NT * 64 * sizeof(f32x4));
+    // LayerNorm gamma | beta of each wave's k-steps, [NW][KPW][32 gamma, 32 beta]: ONE 4-byte load per lane and k-step, handed to
+    // the 16 lanes that need each value through LDS.  (Every lane fetching its own 8 + 8 values was four 1-KB load instructions per
+    // k-step — 40 % of what an LN1+QKV workgroup put through its CU's address path: 64 B per clock is what bounds these launches.)
+    float (*s_gbl)[KPW][64] = reinterpret_cast<float (*)[KPW][64]>(dl_smem + (size_t)(blockDim.x >> 6) * (NT * 64 * sizeof(f32x4) + 16 * 2 * sizeof(float)));
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * (16 * NT), b0 = blockIdx.y * 16;
@@ -110,7 +114,8 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
     }
     Frag<TW> wf[NT][KPW];
     Frag<TW> xft[XT ? KPW : 1];
-    f32x4 xa[XT ? 1 : KPW][2], gb[LN ? KPW : 1][4];
+    f32x4 xa[XT ? 1 : KPW][2];
+    float gbv[LN ? KPW : 1];
     // every weight load first: they come from HBM / MALL (~1 us), the activation and LayerNorm loads behind them are L2 hits,
     // and a wave issues loads only as fast as the CU's address path takes them (24 x 1 KB per wave here)
 #pragma unroll
@@ -128,12 +133,7 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
             xa[i][0] = *reinterpret_cast<const f32x4*>(xp + k);
             xa[i][1] = *reinterpret_cast<const f32x4*>(xp + k + 4);
         }
-        if (LN) {
-            gb[i][0] = *reinterpret_cast<const f32x4*>(p.ln_g + k + g * 8);
-            gb[i][1] = *reinterpret_cast<const f32x4*>(p.ln_g + k + g * 8 + 4);
-            gb[i][2] = *reinterpret_cast<const f32x4*>(p.ln_b + k + g * 8);
-            gb[i][3] = *reinterpret_cast<const f32x4*>(p.ln_b + k + g * 8 + 4);
-        }
+        if (LN) gbv[i] = (lane < 32 ? p.ln_g : p.ln_b - 32)[k + lane];
     }
     WM_DL_STAMP(1);
     float mean = 0.f, rstd = 1.f;
@@ -157,6 +157,8 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
             s_stat[w][r16][0] = sm;
             s_stat[w][r16][1] = sq;
         }
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) s_gbl[w][i][lane] = gbv[i];
         __syncthreads();
         sm = 0.f;
         sq = 0.f;
@@ -185,10 +187,12 @@ __global__ __launch_bounds__(1024) void dec_linear_kernel(DecLinearParams p) {
                 xv[4 + j] = xa[i][1][j];
             }
             if (LN) {
+                const f32x4 gm0 = *reinterpret_cast<const f32x4*>(&s_gbl[w][i][g * 8]), gm1 = *reinterpret_cast<const f32x4*>(&s_gbl[w][i][g * 8 + 4]);
+                const f32x4 bt0 = *reinterpret_cast<const f32x4*>(&s_gbl[w][i][32 + g * 8]), bt1 = *reinterpret_cast<const f32x4*>(&s_gbl[w][i][32 + g * 8 + 4]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    xv[j] = (xv[j] - mean) * rstd * gb[i][0][j] + gb[i][2][j];
-                    xv[4 + j] = (xv[4 + j] - mean) * rstd * gb[i][1][j] + gb[i][3][j];
+                    xv[j] = (xv[j] - mean) * rstd * gm0[j] + bt0[j];
+                    xv[4 + j] = (xv[4 + j] - mean) * rstd * gm1[j] + bt1[j];
                 }
             }
             xf = make_frag<TW>(xv);
@@ -243,7 +247,9 @@ template <typename TW, int KPW> static int launch_dec_linear_t(const DecLinearPa
     static const int nt_force = wm_env("WM_LIN_NT") ? atoi(wm_env("WM_LIN_NT")) : 0;  // dev A/B
     const bool wide = nt_force ? nt_force == 2 : (p.N >= 1024 && nw >= 2);
     const dim3 grid((p.N + (wide ? 31 : 15)) / (wide ? 32 : 16), (p.B + 15) / 16), block(nw * 64);
-    auto smem = [&](int nt) { return (size_t)nw * nt * 64 * sizeof(f32x4) + (size_t)nw * 16 * 2 * sizeof(float); };
+    auto smem = [&](int nt) {  // K-partials, LayerNorm statistics, LayerNorm gamma | beta (see the kernel)
+        return (size_t)nw * nt * 64 * sizeof(f32x4) + (size_t)nw * 16 * 2 * sizeof(float) + (p.ln_g ? (size_t)nw * KPW * 64 * sizeof(float) : 0);
+    };
     if (p.ln_g) {
         if (wide)
             hipLaunchKernelGGL((dec_linear_kernel<TW, KPW, true, 2>), grid, block, smem(2), st, p);
@@ -299,6 +305,169 @@ template int launch_dec_linear<float>(const DecLinearParams&, hipStream_t);
 template int launch_dec_linear<bf16>(const DecLinearParams&, hipStream_t);
 template int launch_dec_linear<f16>(const DecLinearParams&, hipStream_t);
 
+// Scratch of the logits epilogue (fused argmax, stage 1): static LDS in the 16-bit kernel; in the split-fp32 kernel it overlays the
+// activation images once every wave is past its last fragment read.
+template <int NRB> struct LogitsScratch {
+    float (*av)[NRB * 16];  // [8 waves x 4 lane groups][utterance row]: the 4 lane groups of a row meet in LDS, not by cross-lane
+    int (*ai)[NRB * 16];    // shuffles (two ds_bpermute round trips per row block on the kernel's tail)
+    float (*tv)[NRB * 16];  // [8 waves][row]: timestamp-side partials (best value, max, sum of exp)
+    float (*tm)[NRB * 16];
+    float (*ts)[NRB * 16];
+    int (*ti)[NRB * 16];
+    static constexpr size_t bytes = (size_t)(2 * 32 + 4 * 8) * NRB * 16 * 4;
+    __device__ static LogitsScratch carve(unsigned char* base) {
+        LogitsScratch s;
+        float* f = reinterpret_cast<float*>(base);
+        s.av = reinterpret_cast<float (*)[NRB * 16]>(f);
+        s.ai = reinterpret_cast<int (*)[NRB * 16]>(f + 32 * NRB * 16);
+        s.tv = reinterpret_cast<float (*)[NRB * 16]>(f + 64 * NRB * 16);
+        s.tm = reinterpret_cast<float (*)[NRB * 16]>(f + 72 * NRB * 16);
+        s.ts = reinterpret_cast<float (*)[NRB * 16]>(f + 80 * NRB * 16);
+        s.ti = reinterpret_cast<int (*)[NRB * 16]>(f + 88 * NRB * 16);
+        return s;
+    }
+};
+// Shared tail of the logits kernels.  acc[nb][rb][r] = logits[row0 + 16 rb + r16][n0[nb] + 4 g + r]: optional store of the
+// logits, then the fused argmax's stage 1 (and the timestamp-side partials when the rules are on).
+template <int NRB>
+__device__ __forceinline__ void logits_epilogue(const DecLinearParams& p, int CT, const f32x4 (&acc)[2][NRB], const int (&n0)[2],
+                                                const bool (&have)[2], const float (&mk)[2][4], int row0, int nrows, int lane, int w,
+                                                const LogitsScratch<NRB>& sc) {
+    const int r16 = lane & 15, g = lane >> 4;
+    // acc[nb][rb][r] = logits[row0 + 16 rb + r16][n0[nb] + 4 g + r]
+    if (p.out) {
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            const int lr = rb * 16 + r16;
+            if (lr < nrows) {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int n = n0[nb] + g * 4;
+                    if (have[nb] && n < p.ldo) *reinterpret_cast<f32x4*>(p.out + (size_t)(row0 + lr) * p.ldo + n) = acc[nb][rb];
+                }
+            }
+        }
+    }
+    if (p.amax_val) {
+        // fused argmax, stage 1 (whisper_tensor.mojo:431-439: lowest index wins): this workgroup's best of its CT*16
+        // columns per utterance.  Lane-local over 8 columns, 2 butterfly steps over the 4 lanes of a row, LDS over waves.
+        // Timestamp rules on (p.ts_state): "best" is the best admissible TEXT id of the utterance's range, and the workgroups
+        // that cover timestamp ids also reduce the admissible timestamps to (best value, its id, max, sum of exp(v - max)) —
+        // what stage 2 needs to compare the timestamps' probability mass with the best text id (HF rule 5).
+        const bool ts_on = p.ts_state != nullptr;
+        const bool wg_ts = ts_on && (int)((blockIdx.x + 1) * CT * 16) > p.ts_begin;  // workgroup-uniform
+        float (*s_av)[NRB * 16] = sc.av;
+        int (*s_ai)[NRB * 16] = sc.ai;
+        float (*s_tv)[NRB * 16] = sc.tv, (*s_tm)[NRB * 16] = sc.tm, (*s_ts)[NRB * 16] = sc.ts;
+        int (*s_ti)[NRB * 16] = sc.ti;
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+            int t_lo = 0, t_hi = 0x7fffffff, q_lo = 0, q_hi = 0;
+            if (ts_on) {
+                const TsState* stp = p.ts_state + row0 + min(rb * 16 + r16, nrows - 1);
+                t_lo = stp->text_lo;
+                t_hi = stp->text_hi;
+                q_lo = stp->ts_lo;
+                q_hi = stp->ts_hi;
+            }
+            float cand[2][4];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0[nb] + g * 4 + r;
+                    const float v = acc[nb][rb][r] + mk[nb][r];  // 0 or -inf
+                    cand[nb][r] = v;
+                    if (have[nb] && n < p.N && n >= t_lo && n < t_hi && v > bv) {  // n increases through the loop: strict '>' keeps the lowest index
+                        bv = v;
+                        bi = n;
+                    }
+                }
+            if (wg_ts) {
+                float tv = -INFINITY, tsum = 0.f;
+                int ti = 0x7fffffff;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n0[nb] + g * 4 + r;
+                        if (have[nb] && n < p.N && n >= q_lo && n < q_hi && cand[nb][r] > tv) {
+                            tv = cand[nb][r];
+                            ti = n;
+                        }
+                    }
+                float tm = tv;  // the lane's max IS its best value
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n0[nb] + g * 4 + r;
+                        if (have[nb] && n < p.N && n >= q_lo && n < q_hi && cand[nb][r] > -INFINITY) tsum += expf(cand[nb][r] - tm);
+                    }
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {
+                    const float v2 = __shfl_xor(tv, o, 64), m2 = __shfl_xor(tm, o, 64), s2 = __shfl_xor(tsum, o, 64);
+                    const int i2 = __shfl_xor(ti, o, 64);
+                    if (v2 > tv || (v2 == tv && i2 < ti)) {
+                        tv = v2;
+                        ti = i2;
+                    }
+                    const float mn = fmaxf(tm, m2);
+                    tsum = (tsum > 0.f ? tsum * expf(tm - mn) : 0.f) + (s2 > 0.f ? s2 * expf(m2 - mn) : 0.f);
+                    tm = mn;
+                }
+                if (g == 0) {
+                    s_tv[w][rb * 16 + r16] = tv;
+                    s_ti[w][rb * 16 + r16] = ti;
+                    s_tm[w][rb * 16 + r16] = tm;
+                    s_ts[w][rb * 16 + r16] = tsum;
+                }
+            }
+            s_av[w * 4 + g][rb * 16 + r16] = bv;
+            s_ai[w * 4 + g][rb * 16 + r16] = bi;
+        }
+        __syncthreads();
+        if (threadIdx.x < NRB * 16 && (int)threadIdx.x < nrows) {
+            float bv = s_av[0][threadIdx.x];
+            int bi = s_ai[0][threadIdx.x];
+#pragma unroll
+            for (int k = 1; k < 8 * 4; ++k) {
+                const float v2 = s_av[k][threadIdx.x];
+                const int i2 = s_ai[k][threadIdx.x];
+                if (v2 > bv || (v2 == bv && i2 < bi)) {
+                    bv = v2;
+                    bi = i2;
+                }
+            }
+            const size_t o = (size_t)(row0 + threadIdx.x) * p.amax_stride + blockIdx.x;
+            p.amax_val[o] = bv;
+            p.amax_idx[o] = bi;
+            if (wg_ts) {  // the 8 waves' timestamp partials, in wave order (deterministic)
+                float tv = s_tv[0][threadIdx.x], tm = s_tm[0][threadIdx.x], tsum = s_ts[0][threadIdx.x];
+                int ti = s_ti[0][threadIdx.x];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) {
+                    const float v2 = s_tv[k][threadIdx.x], m2 = s_tm[k][threadIdx.x], s2 = s_ts[k][threadIdx.x];
+                    const int i2 = s_ti[k][threadIdx.x];
+                    if (v2 > tv || (v2 == tv && i2 < ti)) {
+                        tv = v2;
+                        ti = i2;
+                    }
+                    const float mn = fmaxf(tm, m2);
+                    tsum = (tsum > 0.f ? tsum * expf(tm - mn) : 0.f) + (s2 > 0.f ? s2 * expf(m2 - mn) : 0.f);
+                    tm = mn;
+                }
+                p.ts_val[o] = tv;
+                p.ts_idx[o] = ti;
+                p.ts_m[o] = tm;
+                p.ts_s[o] = tsum;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Final LayerNorm + tied-embedding logits (whisper.mojo:156-166): logits[B, V] = LN(x)[B, d] · tok_emb[V, d]ᵀ.
 // 80 MB (fp32) / 40 MB (16-bit) of weights per step: the one decoder GEMM that is bandwidth- rather than
@@ -326,8 +495,6 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
     constexpr int PRE = WM_LOGITS_PRE < CHK ? WM_LOGITS_PRE : CHK;  // k-steps of the first tile requested before the staging arithmetic
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     TW* xs = reinterpret_cast<TW*>(smem_raw);  // [NRB*16][PITCH]
-    __shared__ float s_av[8 * 4][NRB * 16];  // [wave][lane group g][utterance row]: the 4 lane groups of a row meet in LDS, not by
-    __shared__ int s_ai[8 * 4][NRB * 16];    // cross-lane shuffles (two ds_bpermute round trips per row block on the kernel's tail)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int row0 = blockIdx.y * NRB * 16;
@@ -466,139 +633,246 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
     else if (have[0])
         body(std::integral_constant<int, 1>{});
     WM_LG_STAMP(3);
-    // acc[nb][rb][r] = logits[row0 + 16 rb + r16][n0[nb] + 4 g + r]
-    if (p.out) {
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) {
-            const int lr = rb * 16 + r16;
-            if (lr < nrows) {
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    const int n = n0[nb] + g * 4;
-                    if (have[nb] && n < p.ldo) *reinterpret_cast<f32x4*>(p.out + (size_t)(row0 + lr) * p.ldo + n) = acc[nb][rb];
-                }
-            }
-        }
-    }
-    if (p.amax_val) {
-        // fused argmax, stage 1 (whisper_tensor.mojo:431-439: lowest index wins): this workgroup's best of its CT*16
-        // columns per utterance.  Lane-local over 8 columns, 2 butterfly steps over the 4 lanes of a row, LDS over waves.
-        // Timestamp rules on (p.ts_state): "best" is the best admissible TEXT id of the utterance's range, and the workgroups
-        // that cover timestamp ids also reduce the admissible timestamps to (best value, its id, max, sum of exp(v - max)) —
-        // what stage 2 needs to compare the timestamps' probability mass with the best text id (HF rule 5).
-        const bool ts_on = p.ts_state != nullptr;
-        const bool wg_ts = ts_on && (int)((blockIdx.x + 1) * CT * 16) > p.ts_begin;  // workgroup-uniform
+    {
+        __shared__ float s_av[8 * 4][NRB * 16];
+        __shared__ int s_ai[8 * 4][NRB * 16];
         __shared__ float s_tv[8][NRB * 16], s_tm[8][NRB * 16], s_ts[8][NRB * 16];
         __shared__ int s_ti[8][NRB * 16];
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) {
-            float bv = -INFINITY;
-            int bi = 0x7fffffff;
-            int t_lo = 0, t_hi = 0x7fffffff, q_lo = 0, q_hi = 0;
-            if (ts_on) {
-                const TsState* stp = p.ts_state + row0 + min(rb * 16 + r16, nrows - 1);
-                t_lo = stp->text_lo;
-                t_hi = stp->text_hi;
-                q_lo = stp->ts_lo;
-                q_hi = stp->ts_hi;
-            }
-            float cand[2][4];
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = n0[nb] + g * 4 + r;
-                    const float v = acc[nb][rb][r] + mk[nb][r];  // 0 or -inf
-                    cand[nb][r] = v;
-                    if (have[nb] && n < p.N && n >= t_lo && n < t_hi && v > bv) {  // n increases through the loop: strict '>' keeps the lowest index
-                        bv = v;
-                        bi = n;
-                    }
-                }
-            if (wg_ts) {
-                float tv = -INFINITY, tsum = 0.f;
-                int ti = 0x7fffffff;
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int n = n0[nb] + g * 4 + r;
-                        if (have[nb] && n < p.N && n >= q_lo && n < q_hi && cand[nb][r] > tv) {
-                            tv = cand[nb][r];
-                            ti = n;
-                        }
-                    }
-                float tm = tv;  // the lane's max IS its best value
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int n = n0[nb] + g * 4 + r;
-                        if (have[nb] && n < p.N && n >= q_lo && n < q_hi && cand[nb][r] > -INFINITY) tsum += expf(cand[nb][r] - tm);
-                    }
-#pragma unroll
-                for (int o = 16; o <= 32; o <<= 1) {
-                    const float v2 = __shfl_xor(tv, o, 64), m2 = __shfl_xor(tm, o, 64), s2 = __shfl_xor(tsum, o, 64);
-                    const int i2 = __shfl_xor(ti, o, 64);
-                    if (v2 > tv || (v2 == tv && i2 < ti)) {
-                        tv = v2;
-                        ti = i2;
-                    }
-                    const float mn = fmaxf(tm, m2);
-                    tsum = (tsum > 0.f ? tsum * expf(tm - mn) : 0.f) + (s2 > 0.f ? s2 * expf(m2 - mn) : 0.f);
-                    tm = mn;
-                }
-                if (g == 0) {
-                    s_tv[w][rb * 16 + r16] = tv;
-                    s_ti[w][rb * 16 + r16] = ti;
-                    s_tm[w][rb * 16 + r16] = tm;
-                    s_ts[w][rb * 16 + r16] = tsum;
-                }
-            }
-            s_av[w * 4 + g][rb * 16 + r16] = bv;
-            s_ai[w * 4 + g][rb * 16 + r16] = bi;
-        }
-        __syncthreads();
-        if (threadIdx.x < NRB * 16 && (int)threadIdx.x < nrows) {
-            float bv = s_av[0][threadIdx.x];
-            int bi = s_ai[0][threadIdx.x];
-#pragma unroll
-            for (int k = 1; k < 8 * 4; ++k) {
-                const float v2 = s_av[k][threadIdx.x];
-                const int i2 = s_ai[k][threadIdx.x];
-                if (v2 > bv || (v2 == bv && i2 < bi)) {
-                    bv = v2;
-                    bi = i2;
-                }
-            }
-            const size_t o = (size_t)(row0 + threadIdx.x) * p.amax_stride + blockIdx.x;
-            p.amax_val[o] = bv;
-            p.amax_idx[o] = bi;
-            if (wg_ts) {  // the 8 waves' timestamp partials, in wave order (deterministic)
-                float tv = s_tv[0][threadIdx.x], tm = s_tm[0][threadIdx.x], tsum = s_ts[0][threadIdx.x];
-                int ti = s_ti[0][threadIdx.x];
-#pragma unroll
-                for (int k = 1; k < 8; ++k) {
-                    const float v2 = s_tv[k][threadIdx.x], m2 = s_tm[k][threadIdx.x], s2 = s_ts[k][threadIdx.x];
-                    const int i2 = s_ti[k][threadIdx.x];
-                    if (v2 > tv || (v2 == tv && i2 < ti)) {
-                        tv = v2;
-                        ti = i2;
-                    }
-                    const float mn = fmaxf(tm, m2);
-                    tsum = (tsum > 0.f ? tsum * expf(tm - mn) : 0.f) + (s2 > 0.f ? s2 * expf(m2 - mn) : 0.f);
-                    tm = mn;
-                }
-                p.ts_val[o] = tv;
-                p.ts_idx[o] = ti;
-                p.ts_m[o] = tm;
-                p.ts_s[o] = tsum;
-            }
-        }
+        LogitsScratch<NRB> sc;
+        sc.av = s_av;
+        sc.ai = s_ai;
+        sc.tv = s_tv;
+        sc.tm = s_tm;
+        sc.ts = s_ts;
+        sc.ti = s_ti;
+        logits_epilogue<NRB>(p, CT, acc, n0, have, mk, row0, nrows, lane, w, sc);
     }
     WM_LG_STAMP(4);
 }
 #undef WM_LG_STAMP
+int dec_logits_tiles_per_wg(int N);
+int dec_logits_parts(int N);
+// ------------------------------------------------------------------------------------------------------------
+// The same projection for FP32 weights (decoder_fp32 / all-fp32 models) on the bf16 MFMA pipe.
+// With fp32 operands the kernel above is MFMA-bound, not HBM-bound: 2·64·51 865·384 = 2.55 GFLOP per step against the 157 TFLOP/s
+// of v_mfma_f32_16x16x4_f32 (32 cycles per SIMD for a 16x16x4 block) is 16 us at best, 20.5 us for the busiest SIMD's four
+// column tiles — measured 38 us per launch for an 80 MB stream that HBM delivers in 13.  gfx950 has no reduced-precision fp32
+// path, but every fp32 value is EXACTLY the sum of three bf16 values (8 + 8 + 8 significant bits, taken by truncation:
+// x = h + m + l with l = x - h - m exact), and a bf16 x bf16 product is exact in the MFMA's fp32 accumulator.  So
+//     w·x = (wh + wm + wl)(xh + xm + xl) ≈ wh·xh + wh·xm + wm·xh + wh·xl + wm·xm + wl·xh
+// — six v_mfma_f32_16x16x32_bf16 (16 cycles each, K = 32) instead of eight fp32 MFMAs of K = 4 (32 cycles each): 96 against 256
+// cycles per 16x16x32 block.  The three dropped terms are <= 2^-24 |w·x| each, i.e. at the rounding error of the fp32 product
+// itself; accumulation stays fp32.  The weights are split in registers as they arrive (44 VALU operations per fragment, hidden in
+// the MFMAs' issue gaps); the normalised activations are split ONCE per workgroup and parked in LDS as three bf16 images.
+struct Split3 {
+    bf16x8 h, m, l;
+};
+__device__ __forceinline__ Split3 split3(const f32x8& x) {
+    typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+    u16x8 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const unsigned u = __float_as_uint(x[j]);
+        const unsigned uh = u & 0xffff0000u;  // top 8 significant bits (truncation keeps the sign: the remainders share it)
+        const float r1 = x[j] - __uint_as_float(uh);  // exact
+        const unsigned um = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(um);  // exact, <= 8 significant bits left: a bf16 value
+        h[j] = (unsigned short)(uh >> 16);
+        m[j] = (unsigned short)(um >> 16);
+        l[j] = (unsigned short)(__float_as_uint(r2) >> 16);
+    }
+    Split3 s;
+    s.h = __builtin_bit_cast(bf16x8, h);
+    s.m = __builtin_bit_cast(bf16x8, m);
+    s.l = __builtin_bit_cast(bf16x8, l);
+    return s;
+}
+__device__ __forceinline__ f32x4 mma_bf16(const bf16x8& a, const bf16x8& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int KD /* d_model/128 */, int NRB>
+__global__ __launch_bounds__(512) void dec_logits_split_kernel(DecLinearParams p, int CT) {
+    // Geometry as dec_logits_kernel: 8 waves, wave w owns column tiles w and w + 8 of the workgroup's CT <= 16, all NRB*16 rows.
+    constexpr int K = KD * 128;
+    // row pitch of one bf16 activation image: ≡ 8 dwords (mod 64) — the 16 fragment rows of a ds_read_b128 lane group
+    // ({rows 0-3, 12-15 at k-group g} ∪ {rows 4-11 at g + 1}) then sit on 16 disjoint 4-bank groups, like the ≡ 40 pitch above
+    constexpr int PITCH = K + 16;
+    constexpr int KS = KD * 4;      // k-steps of 32
+    constexpr int CHK = KD == 1 ? 2 : KS / 2;  // k-steps of a tile whose fp32 weight fragments are in flight together (8 VGPRs each)
+    constexpr int IMG = NRB * 16 * PITCH;  // elements per image
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* xs = reinterpret_cast<bf16*>(smem_raw);                                        // [3][NRB*16][PITCH]: h, m, l
+    float* s_gb = reinterpret_cast<float*>(smem_raw + (size_t)3 * IMG * sizeof(bf16));  // [2][K] LN gamma / beta
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.y * NRB * 16;
+    if (p.ts && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ts_put(p.ts, p.ts_id, 2);
+#ifdef WM_DEV
+#define WM_LG_STAMP(k) do { if (p.dbg && (threadIdx.x & 63) == 0) p.dbg[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define WM_LG_STAMP(k) do { } while (0)
+#endif
+    WM_LG_STAMP(0);
+    const int nrows = min(NRB * 16, p.B - row0);
+    int n0[2];
+    bool have[2];
+    const float* wp[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int t = w + 8 * nb;
+        n0[nb] = (blockIdx.x * CT + t) * 16;
+        have[nb] = __builtin_amdgcn_readfirstlane((int)(t < CT && n0[nb] < p.N)) != 0;
+        int wr = n0[nb] + r16;
+        wr = wr < p.N ? wr : p.N - 1;
+        wp[nb] = (const float*)p.W + (size_t)wr * K + g * 8;
+    }
+    if (!have[1]) wp[1] = wp[0];  // unconditional loads (see dec_logits_kernel): a wave without a second tile re-requests its first
+    f32x8 wf[2][CHK];
+    auto wload = [&](int nb, int ks) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wp[nb] + ks * 32), b = *reinterpret_cast<const f32x4*>(wp[nb] + ks * 32 + 4);
+        return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    };
+    float mk[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    constexpr int PRE = CHK < 4 ? CHK : 4;  // k-steps of the first tile requested before the staging arithmetic
+    {  // LN + three-way split -> LDS.  thread t: row t>>3 (+64 per pass), eighth t&7 of the row, float4 index q + 8*i
+        for (int rbase = 0; rbase < NRB * 16; rbase += 64) {
+            const int lr = rbase + (threadIdx.x >> 3), q = threadIdx.x & 7;
+            f32x4 v[KD * 4];
+            const bool mine = lr < NRB * 16;
+            if (mine) {
+                const int row = min(lr, nrows - 1);
+                const float* xr = p.x + (size_t)(row0 + row) * p.ldx;
+#pragma unroll
+                for (int i = 0; i < KD * 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * (q + 8 * i));
+            }
+            if (rbase == 0) {
+                f32x4 gbv = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int gi = threadIdx.x;  // float4 index into [gamma | beta]
+                if (gi < K / 2) gbv = *reinterpret_cast<const f32x4*>((gi < K / 4 ? p.ln_g : p.ln_b - K) + 4 * gi);
+                if (p.amax_mask) {
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mk[nb][r] = p.amax_mask[min(n0[nb] + g * 4 + r, p.N - 1)];
+                }
+                if (gi < K / 2) *reinterpret_cast<f32x4*>(s_gb + 4 * gi) = gbv;
+                WM_LG_STAMP(5);
+                __syncthreads();
+                WM_LG_STAMP(6);
+#pragma unroll
+                for (int i = 0; i < PRE; ++i) wf[0][i] = wload(0, i);
+            }
+            if (mine) {
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int i = 0; i < KD * 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        sm += v[i][j];
+                        sq += v[i][j] * v[i][j];
+                    }
+#pragma unroll
+                for (int o = 1; o <= 4; o <<= 1) {
+                    sm += __shfl_xor(sm, o, 64);
+                    sq += __shfl_xor(sq, o, 64);
+                }
+                const float mean = sm / (float)K;
+                const float var = (sq / (float)K) - (mean * mean);
+                const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+                for (int i = 0; i < KD * 4; ++i) {
+                    const int k = 4 * (q + 8 * i);
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(s_gb + k), bt = *reinterpret_cast<const f32x4*>(s_gb + K + k);
+                    typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+                    u16x4 oh, om, ol;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float y = (v[i][j] - mean) * rstd * gm[j] + bt[j];  // the fp32 operand the exact kernel multiplies
+                        const unsigned uh = __float_as_uint(y) & 0xffff0000u;
+                        const float r1 = y - __uint_as_float(uh);
+                        const unsigned um = __float_as_uint(r1) & 0xffff0000u;
+                        const float r2 = r1 - __uint_as_float(um);
+                        oh[j] = (unsigned short)(uh >> 16);
+                        om[j] = (unsigned short)(um >> 16);
+                        ol[j] = (unsigned short)(__float_as_uint(r2) >> 16);
+                    }
+                    *reinterpret_cast<u16x4*>(&xs[lr * PITCH + k]) = oh;
+                    *reinterpret_cast<u16x4*>(&xs[IMG + lr * PITCH + k]) = om;
+                    *reinterpret_cast<u16x4*>(&xs[2 * IMG + lr * PITCH + k]) = ol;
+                }
+            }
+        }
+    }
+    WM_LG_STAMP(1);
+    __syncthreads();
+    WM_LG_STAMP(2);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int i = (nb == 0 ? PRE : 0); i < CHK; ++i) wf[nb][i] = wload(nb, i);
+
+    f32x4 acc[2][NRB];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc[nb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto body = [&](auto NB) {
+        constexpr int nbn = decltype(NB)::value;
+#pragma unroll
+        for (int c = 0; c < KS / CHK; ++c) {
+#pragma unroll
+            for (int i = 0; i < CHK; ++i) {
+                Split3 ws[nbn];
+#pragma unroll
+                for (int nb = 0; nb < nbn; ++nb) {
+                    ws[nb] = split3(wf[nb][i]);
+                    // rolling prefetch: the register set just split takes the same k-step of the next chunk
+                    if (c + 1 < KS / CHK) wf[nb][i] = wload(nb, (c + 1) * CHK + i);
+                }
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    const int xo = (rb * 16 + r16) * PITCH + (c * CHK + i) * 32 + g * 8;
+                    const bf16x8 xh = *reinterpret_cast<const bf16x8*>(&xs[xo]);
+                    const bf16x8 xm = *reinterpret_cast<const bf16x8*>(&xs[IMG + xo]);
+                    const bf16x8 xl = *reinterpret_cast<const bf16x8*>(&xs[2 * IMG + xo]);
+#pragma unroll
+                    for (int nb = 0; nb < nbn; ++nb) {  // smallest terms first
+                        f32x4 a = acc[nb][rb];
+                        a = mma_bf16(ws[nb].l, xh, a);
+                        a = mma_bf16(ws[nb].h, xl, a);
+                        a = mma_bf16(ws[nb].m, xm, a);
+                        a = mma_bf16(ws[nb].m, xh, a);
+                        a = mma_bf16(ws[nb].h, xm, a);
+                        a = mma_bf16(ws[nb].h, xh, a);
+                        acc[nb][rb] = a;
+                    }
+                }
+            }
+        }
+    };
+    if (have[1])
+        body(std::integral_constant<int, 2>{});
+    else if (have[0])
+        body(std::integral_constant<int, 1>{});
+    WM_LG_STAMP(3);
+    __syncthreads();  // every wave is past its last fragment read: the epilogue's scratch overlays the activation images
+    static_assert(LogitsScratch<NRB>::bytes <= (size_t)3 * IMG * sizeof(bf16), "epilogue scratch must fit the activation images");
+    logits_epilogue<NRB>(p, CT, acc, n0, have, mk, row0, nrows, lane, w, LogitsScratch<NRB>::carve(smem_raw));
+    WM_LG_STAMP(4);
+}
+#undef WM_LG_STAMP
+template <int KD, int NRB> static int launch_dec_logits_split_t(const DecLinearParams& p, hipStream_t st) {
+    const size_t lds = (size_t)3 * NRB * 16 * (KD * 128 + 16) * sizeof(bf16) + (size_t)2 * KD * 128 * sizeof(float);
+    if (lds > 48 * 1024)
+        if (const hipError_t e = ensure_dyn_lds<&dec_logits_split_kernel<KD, NRB>>((int)lds); e != hipSuccess)
+            return launch_hip_failed("logits kernel (split fp32): dynamic LDS attribute", e);
+    const int ct = dec_logits_tiles_per_wg(p.N);
+    dim3 grid(dec_logits_parts(p.N), (p.B + NRB * 16 - 1) / (NRB * 16));
+    hipLaunchKernelGGL((dec_logits_split_kernel<KD, NRB>), grid, dim3(512), lds, st, p, ct);
+    return WM_LAUNCH_OK;
+}
+
 // column tiles (of 16) per workgroup: the smallest count that covers the vocabulary with <= 256 workgroups, at most 16
 int dec_logits_tiles_per_wg(int N) {
     const int tiles = (N + 15) / 16;
@@ -626,6 +900,15 @@ template <typename TW> int launch_dec_logits(const DecLinearParams& p, hipStream
     if ((p.K & 127) != 0 || (kd != 1 && kd != 3 && kd != 4)) return launch_refuse("dec_logits: d_model must be 128, 384 or 512");
     if (!p.ln_g || !p.ln_b) return launch_refuse("dec_logits: the final LayerNorm's gamma / beta are required");
     if (p.amax_val && p.amax_stride < dec_logits_parts(p.N)) return launch_refuse("dec_logits: amax_stride is smaller than the partials per utterance");
+    if constexpr (sizeof(TW) == 4) {
+        // fp32 weights: the three-way bf16 split (d_model 128 / 384: three activation images fit the 160 KB of LDS); d_model 512
+        // keeps the exact-fp32 MFMA kernel.  WM_LOGITS_EXACT (developer build) forces the exact kernel for A/B runs.
+        static const bool exact = wm_env("WM_LOGITS_EXACT") != nullptr;
+        if (!exact && (kd == 1 || kd == 3)) {
+            if (p.B <= 16) return kd == 1 ? launch_dec_logits_split_t<1, 1>(p, st) : launch_dec_logits_split_t<3, 1>(p, st);
+            return kd == 1 ? launch_dec_logits_split_t<1, 4>(p, st) : launch_dec_logits_split_t<3, 4>(p, st);
+        }
+    }
     if (p.B <= 16) {
         if (kd == 1) return launch_dec_logits_t<TW, 1, 1>(p, st);
         if (kd == 3) return launch_dec_logits_t<TW, 3, 1>(p, st);
@@ -985,6 +1268,13 @@ __global__ __launch_bounds__(1024) void argmax_step_kernel(ArgmaxParams p) {
     const int b = blockIdx.x;
     if (p.ts && b == 0 && threadIdx.x == 0) ts_put(p.ts, p.ts_id, 3);
     const int pos0 = p.emb_out ? p.pos[b] : 0;  // read before thread 0 advances it (the reductions below synchronise)
+    if (p.host_progress && b == 0 && threadIdx.x == 0) {
+        // finishes of EARLIER steps are complete (their launches ended); this step's may or may not be counted yet: a lower bound.
+        // System-scope stores to pinned host memory: visible to the polling host without any stream synchronisation.
+        const int fin = __hip_atomic_load(&p.ctl->n_finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p.host_progress[0], fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&p.host_progress[1], p.ctl->len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     float best;
     int idx;
     if (p.pval)

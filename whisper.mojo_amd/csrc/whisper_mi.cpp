@@ -15,7 +15,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <unordered_set>
 #include <vector>
@@ -199,6 +202,13 @@ struct wm_model {
     wm_state* cached = nullptr;           // slot 0: the state behind wm_transcribe / wm_transcribe_submit(slot 0)
     wm_state* slots[NSLOT - 1] = {};  // slots 1..7: further pipeline stages (wm_transcribe_submit)
     std::unordered_set<wm_state*> states;  // every state created on this model (wm_state_new), freed with it
+    // Loop pump (natural-stop passes of wm_transcribe_submit): one host thread per model that keeps each pending pass's greedy loop
+    // two sub-chunks ahead of the GPU and stops enqueueing once the device reports every utterance finished (whisper.mojo:206-207).
+    std::thread pump;
+    std::mutex pump_mu;
+    std::condition_variable pump_cv;
+    std::vector<wm_state*> pump_work;  // passes whose loop is not fully enqueued yet
+    bool pump_quit = false;
 };
 
 struct wm_state {
@@ -230,6 +240,22 @@ struct wm_state {
     bool graph_shares = false;
     int trace_id = 1;       // slot + 1: tags this state's entries in the developer timeline
     int pend_total = 0;     // ids per utterance of the pending pass
+    // Greedy loop of the pending pass, enqueued in sub-chunks of LOOP_CHUNK steps with at most two sub-chunks queued ahead of the GPU
+    // (natural stop only; a fixed-length pass is enqueued whole).  h_prog: pinned, device-mapped [finished utterances, cache length],
+    // written by every step's argmax launch.
+    volatile int* h_prog = nullptr;
+    int* d_prog = nullptr;
+    int loop_total = 0, loop_enq = 0;  // steps the loop may run / steps enqueued so far
+    int chunk_k = 0;                   // sub-chunks enqueued
+    hipEvent_t chunk_ev[2] = {nullptr, nullptr};
+    std::atomic<bool> enq_done{true};  // the pending pass is fully enqueued (its `done` events are recorded)
+    int enq_rc = 0;                    // status of the pump's enqueues
+    std::string enq_err;
+    int last_steps = -1;               // loop steps enqueued for the most recent completed pass (wm_transcribe_steps)
+    struct LoopOpts {
+        int eot = 0, ignore_eot = 0;
+        TsRules rules{};
+    } loop_opts;
     const float* last_mel = nullptr;  // device pointer of the last encoded batch (bench replays the encoder on it)
     // encoder arena (sized for Bc utterances)
     DevBuf mel_dev, mel_t, h1, x, xn, qkv, ao, hid, enc_t;
@@ -373,6 +399,14 @@ extern "C" void wm_model_free(wm_model* m) {
     }
     if (!m) return;
     (void)hipSetDevice(m->device);
+    if (m->pump.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(m->pump_mu);
+            m->pump_quit = true;
+        }
+        m->pump_cv.notify_all();
+        m->pump.join();
+    }
     // the model owns every state created on it (pipeline slots and the caller's KVCaches): a handle the caller still holds
     // becomes stale — wm_state_free / wm_decode_step on it is a checked no-op / error, not a use after free
     while (!m->states.empty()) wm_state_free(*m->states.begin());
@@ -675,6 +709,11 @@ extern "C" void wm_state_free(wm_state* s) {
         std::lock_guard<std::mutex> lk(g_states_mu);
         if (!g_live_states.erase(s)) return;  // stale handle: its model was freed (and took the state with it)
     }
+    {  // the loop pump must not touch this state any more (it works under this mutex)
+        std::lock_guard<std::mutex> lk(s->m->pump_mu);
+        auto& wq = s->m->pump_work;
+        wq.erase(std::remove(wq.begin(), wq.end(), s), wq.end());
+    }
     s->m->states.erase(s);
     if (s->m->cached == s) s->m->cached = nullptr;
     for (auto& sl : s->m->slots)
@@ -692,7 +731,10 @@ extern "C" void wm_state_free(wm_state* s) {
         if (ln.done) (void)hipEventDestroy(ln.done);
     }
     if (s->enc_done) (void)hipEventDestroy(s->enc_done);
+    for (auto& ev : s->chunk_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
+    if (s->h_prog) (void)hipHostFree((void*)s->h_prog);
     DevBuf* bs[] = {&s->mel_dev, &s->mel_t, &s->h1, &s->x, &s->xn, &s->qkv, &s->ao, &s->hid, &s->enc_t, &s->enc_f,
                     &s->cross_kv, &s->self_kv, &s->dx, &s->dq, &s->dattn, &s->dhid, &s->part_o, &s->part_ml, &s->logits, &s->amax_val, &s->amax_idx, &s->ts_state, &s->ts_val, &s->ts_idx, &s->ts_m, &s->ts_s, &s->mask_steady, &s->mask_begin,
                     &s->tok, &s->pos, &s->tok_rows, &s->pos_rows, &s->ctl, &s->out_tokens, &s->n_tokens, &s->finished};
@@ -818,6 +860,10 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
         }
         hipError_t e = hipEventCreateWithFlags(&s->enc_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_ctl, sizeof(StepCtl) * 8, 0);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_prog, 64, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&s->d_prog, (void*)s->h_prog, 0);
+        for (auto& ev : s->chunk_ev)
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         if (e != hipSuccess) {
             wm_state_free(s);
             return fail(WM_E_HIP, "event: %s", hipGetErrorString(e));
@@ -1288,6 +1334,7 @@ static ArgmaxParams argmax_params(wm_model* m, wm_state* s, const DecView& v, bo
     a.pos = s->pos.as<int>() + v.b0;
     a.ts = (long long*)m->ts_buf.p;
     a.ts_id = s->trace_id;
+    if (advance) a.host_progress = s->d_prog;  // the greedy loop's steps report (finished, cache length) to the host
     if (embed_next) {
         a.emb_tok = m->tok_emb_f.as<float>();
         a.emb_pos = m->dec_pos.as<float>();
@@ -1354,6 +1401,100 @@ extern "C" int wm_decode_step(wm_model* m, wm_state* s, const int32_t* tokens, i
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+// ---- greedy-loop enqueue machinery (used by transcribe_decode and the loop pump) -----------------------------------------------
+static const int LOOP_CHUNK = 8;  // graph replays per sub-chunk; two sub-chunks (16 steps) are queued ahead of the GPU
+
+// n more steps of the pending pass's loop on the state's lane streams (captured graph, or eager launches in the developer build)
+static int enqueue_loop_steps(wm_model* m, wm_state* s, int n) {
+    const TsRules* rp = s->loop_opts.rules.tb > 0 ? &s->loop_opts.rules : nullptr;
+    for (int k = 0; k < n; ++k, ++s->loop_enq) {
+        const int it = s->loop_enq;
+        for (auto& ln : s->lanes) {
+            if (trace_events_on() && it % 10 == 9) trace_mark(ln.st, "state %p lane %d step %d", (void*)s, ln.b0, it);
+            if (ln.graph[0] && s->graphs_valid) {
+                const hipError_t e = hipGraphLaunch(ln.graph[it % wm_state::Lane::NEXEC], ln.st);
+                if (e != hipSuccess) return fail(WM_E_HIP, "hipGraphLaunch: %s", hipGetErrorString(e));
+            } else {
+                const DecView v{ln.b0, ln.nb, ln.st, ln.ctl};
+                WMCHK(decode_core(m, s, v, true, false, s->mask_steady.as<float>(), 1, false, rp));
+                launch_argmax_step(argmax_params(m, s, v, true, s->loop_opts.eot, s->loop_opts.ignore_eot, true, true, rp), v.st);
+            }
+        }
+    }
+    return 0;
+}
+// the pending pass is fully enqueued: its completion events go behind the last step
+static int finish_enqueue(wm_model* m, wm_state* s) {
+    (void)m;
+    int rc = 0;
+    for (auto& ln : s->lanes) {
+        trace_mark(ln.st, "state %p lane %d decode end", (void*)s, ln.b0);
+        const hipError_t e = hipEventRecord(ln.done, ln.st);
+        if (e != hipSuccess && !rc) rc = fail(WM_E_HIP, "hipEventRecord: %s", hipGetErrorString(e));
+    }
+    if (!rc && hipGetLastError() != hipSuccess) rc = fail(WM_E_HIP, "a launch of the greedy loop failed");
+    s->last_steps = s->loop_enq;
+    if (rc && !s->enq_rc) {
+        s->enq_rc = rc;
+        s->enq_err = g_err;
+    }
+    s->enq_done.store(true);
+    return rc;
+}
+static int enqueue_chunk(wm_model* m, wm_state* s) {
+    const int n = std::min(LOOP_CHUNK, s->loop_total - s->loop_enq);
+    WMCHK(enqueue_loop_steps(m, s, n));
+    HIPCHK(hipEventRecord(s->chunk_ev[s->chunk_k & 1], s->lanes[0].st));
+    ++s->chunk_k;
+    return 0;
+}
+// One decision of the loop pump for state s: once sub-chunk k-2 has completed, either stop (every utterance finished, or the loop
+// bound reached) or enqueue sub-chunk k.  Returns 1 when it did something, 0 when sub-chunk k-2 is still running (non-blocking
+// form), < 0 on error (the pass is then closed with enq_rc set).
+static int pump_step(wm_model* m, wm_state* s, bool block) {
+    hipEvent_t ev = s->chunk_ev[s->chunk_k & 1];  // recorded behind sub-chunk chunk_k - 2
+    hipError_t e = block ? hipEventSynchronize(ev) : hipEventQuery(ev);
+    if (e == hipErrorNotReady) return 0;
+    int rc = e == hipSuccess ? 0 : fail(WM_E_HIP, "loop pump: %s", hipGetErrorString(e));
+    if (!rc) {
+        const bool all_done = s->h_prog[0] >= s->B;  // a lower bound of the finished count: never stops a running utterance
+        if (all_done || s->loop_enq >= s->loop_total) {
+            rc = finish_enqueue(m, s);
+            return rc ? -1 : 1;
+        }
+        rc = enqueue_chunk(m, s);
+        if (!rc) return 1;
+    }
+    s->enq_rc = rc;
+    s->enq_err = g_err;
+    (void)finish_enqueue(m, s);
+    return -1;
+}
+static void pump_main(wm_model* m) {
+    (void)hipSetDevice(m->device);
+    std::unique_lock<std::mutex> lk(m->pump_mu);
+    for (;;) {
+        m->pump_cv.wait(lk, [&] { return m->pump_quit || !m->pump_work.empty(); });
+        if (m->pump_quit) return;
+        bool progressed = false;
+        for (size_t i = 0; i < m->pump_work.size();) {
+            wm_state* s = m->pump_work[i];
+            if (pump_step(m, s, false) != 0) progressed = true;
+            if (s->enq_done.load()) {
+                m->pump_work.erase(m->pump_work.begin() + (long)i);
+                m->pump_cv.notify_all();  // wm_transcribe_wait may be waiting for this pass to be fully enqueued
+            } else {
+                ++i;
+            }
+        }
+        if (!progressed) {  // every pending sub-chunk still running: they take milliseconds
+            lk.unlock();
+            std::this_thread::sleep_for(std::chrono::microseconds(100));
+            lk.lock();
+        }
+    }
 }
 
 // ---- Whisper.transcribe: whisper.mojo:184-223 ------------------------------------------------------------------------
@@ -1464,53 +1605,39 @@ static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, 
         for (auto& ln : s->lanes) (void)hipStreamSynchronize(ln.st);
         fprintf(stderr, "[wm] encoder wait + prefill (+graph capture if any): %.3f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count() * 1e3);
     }
-    StepCtl* h_ctl = s->h_ctl;
-    int rc = 0;
-    const auto t_loop0 = std::chrono::steady_clock::now();
-    for (int it = 0; it < o->max_loop && !rc; ++it) {
-        if (allow_poll && !o->ignore_eot && (it % 8) == 0) {  // "if next_token == eot: break", for the whole batch
-            int fin = 0;
-            for (auto& ln : s->lanes) {
-                hipError_t e = hipMemcpyAsync(h_ctl, ln.ctl, sizeof(StepCtl), hipMemcpyDeviceToHost, ln.st);
-                if (e == hipSuccess) e = hipStreamSynchronize(ln.st);
-                if (e != hipSuccess) {
-                    rc = fail(WM_E_HIP, "poll: %s", hipGetErrorString(e));
-                    break;
-                }
-                fin += h_ctl->n_finished;
-            }
-            if (rc || fin >= B) break;
-        }
-        for (auto& ln : s->lanes) {
-            if (trace_events_on() && it % 10 == 9) trace_mark(ln.st, "state %p lane %d step %d", (void*)s, ln.b0, it);
-            if (ln.graph[0] && !no_graph) {
-                hipError_t e = hipGraphLaunch(ln.graph[it % wm_state::Lane::NEXEC], ln.st);
-                if (e != hipSuccess) {
-                    rc = fail(WM_E_HIP, "hipGraphLaunch: %s", hipGetErrorString(e));
-                    break;
-                }
-            } else {
-                const DecView v{ln.b0, ln.nb, ln.st, ln.ctl};
-                rc = decode_core(m, s, v, true, false, s->mask_steady.as<float>(), 1, false, rp);
-                if (rc) break;
-                launch_argmax_step(argmax_params(m, s, v, true, o->eot, o->ignore_eot, true, true, rp), v.st);
-            }
-        }
+    // The loop itself.  Fixed-length passes (ignore_eot: the bench's "fixed" mode) and short loops are enqueued whole.  With the
+    // reference's stop rule the loop goes out in sub-chunks of LOOP_CHUNK graph replays, two sub-chunks ahead of the GPU; before
+    // each further sub-chunk the host reads the (finished, length) pair the argmax launches write to pinned memory — no stream
+    // synchronisation, the GPU never runs dry — and stops enqueueing once every utterance has emitted eot: "if next_token == eot:
+    // break" (whisper.mojo:206-207) for the whole batch, at most two sub-chunks late.
+    s->loop_total = o->max_loop;
+    s->loop_enq = 0;
+    s->chunk_k = 0;
+    s->loop_opts.eot = o->eot;
+    s->loop_opts.ignore_eot = o->ignore_eot;
+    s->loop_opts.rules = rules;
+    s->enq_rc = 0;
+    s->enq_err.clear();
+    s->h_prog[0] = 0;
+    s->h_prog[1] = 0;
+    const bool natural = !o->ignore_eot && s->lanes.size() == 1 && o->max_loop > 2 * LOOP_CHUNK && !no_graph;
+    s->enq_done.store(false);
+    if (!natural) {
+        WMCHK(enqueue_loop_steps(m, s, o->max_loop));
+        return finish_enqueue(m, s);
     }
-    if (rc) return rc;
-    if (trace_phase) {
-        const auto t1 = std::chrono::steady_clock::now();
-        for (auto& ln : s->lanes) (void)hipStreamSynchronize(ln.st);
-        const auto t2 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[wm] decode loop: %d iterations x %zu lanes: host enqueue %.1f us/iteration, drain %.1f ms\n", o->max_loop,
-                s->lanes.size(), std::chrono::duration<double>(t1 - t_loop0).count() * 1e6 / std::max(1, o->max_loop),
-                std::chrono::duration<double>(t2 - t1).count() * 1e3);
+    WMCHK(enqueue_chunk(m, s));
+    WMCHK(enqueue_chunk(m, s));
+    if (allow_poll) {  // the synchronous entry pumps its own loop
+        while (!s->enq_done.load()) WMCHK(pump_step(m, s, true) < 0 ? s->enq_rc : 0);
+        return 0;
     }
-    for (auto& ln : s->lanes) {
-        trace_mark(ln.st, "state %p lane %d decode end", (void*)s, ln.b0);
-        HIPCHK(hipEventRecord(ln.done, ln.st));
+    {  // pipelined entry: the model's pump thread carries on; wm_transcribe_wait waits for it
+        std::lock_guard<std::mutex> lk(m->pump_mu);
+        if (!m->pump.joinable()) m->pump = std::thread(pump_main, m);
+        m->pump_work.push_back(s);
     }
-    HIPCHK(hipGetLastError());
+    m->pump_cv.notify_all();
     return 0;
 }
 
@@ -1586,6 +1713,15 @@ static int submit_on(wm_model* m, wm_state** slot, const float* mel, int mel_on_
 static int wait_on(wm_model* m, wm_state* s, int32_t* tokens_out, int32_t* n_tokens) {
     if (!s || !s->pending) return fail(WM_E_STATE, "nothing was submitted on this slot");
     HIPCHK(hipSetDevice(m->device));
+    if (!s->enq_done.load()) {  // the loop pump is still feeding this pass
+        std::unique_lock<std::mutex> lk(m->pump_mu);
+        m->pump_cv.wait(lk, [&] { return s->enq_done.load(); });
+    }
+    if (s->enq_rc) {
+        s->pending = false;
+        for (auto& ln : s->lanes) (void)hipStreamSynchronize(ln.st);
+        return fail(s->enq_rc, "%s", s->enq_err.c_str());
+    }
     for (auto& ln : s->lanes) HIPCHK(hipEventSynchronize(ln.done));
     const int total = s->pend_total;
     HIPCHK(hipMemcpy2D(tokens_out, (size_t)total * 4, s->out_tokens.p, (size_t)s->out_stride * 4, (size_t)total * 4, s->B, hipMemcpyDeviceToHost));
@@ -1614,6 +1750,12 @@ extern "C" int wm_transcribe_submit(wm_model* m, int slot, const float* mel, int
 extern "C" int wm_transcribe_wait(wm_model* m, int slot, int32_t* tokens_out, int32_t* n_tokens) {
     if (!m || !tokens_out || !n_tokens || slot < 0 || slot >= wm_model::NSLOT) return fail(WM_E_ARG, "bad argument");
     return wait_on(m, slot == 0 ? m->cached : m->slots[slot - 1], tokens_out, n_tokens);
+}
+
+extern "C" int wm_transcribe_steps(wm_model* m, int slot) {
+    if (!m || slot < 0 || slot >= wm_model::NSLOT) return -1;
+    wm_state* s = slot == 0 ? m->cached : m->slots[slot - 1];
+    return (s && state_is_live(s)) ? s->last_steps : -1;
 }
 
 // ---- log-mel front end: 16 kHz PCM -> [n_mels, n_frames]  (export_weights.py:100-116 delegates this to
@@ -1996,7 +2138,7 @@ extern "C" int wm_op_matmul_nt(float* C, const float* A, const float* Bm, const 
             return false;
         };
         int Kp = (K + 127) / 128 * 128;
-        while (!splittable(Kp)) Kp += 128;
+        while (Kp <= 2048 && !splittable(Kp)) Kp += 128;  // (bounded: no K above 2048 splits, and an unbounded search overflowed)
         if (Kp > 2048) return fail(WM_E_ARG, "K too large for the skinny path (<= 2048)");
         std::vector<float> Apad((size_t)M * Kp, 0.f), Bpad((size_t)N * Kp, 0.f);
         for (int i = 0; i < M; ++i) memcpy(&Apad[(size_t)i * Kp], A + (size_t)i * K, (size_t)K * 4);

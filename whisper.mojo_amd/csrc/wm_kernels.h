@@ -223,6 +223,9 @@ struct ArgmaxParams {
     int eot, ignore_eot;
     int advance;  // != 0: also do the end-of-step bookkeeping (len += 1, pos[b] += 1)
     int* pos;
+    // non-null: a host-visible (pinned, device-mapped) pair the launch updates for the host's early-exit check, no stream
+    // synchronisation needed: [0] = utterances finished BEFORE this step (never more than the truth), [1] = loop steps completed
+    int* host_progress;
     long long* ts;  // developer timeline (null = off)
     int ts_id;
     // non-null: also write the NEXT step's input row x[b] = tok_emb[chosen id] + pos_emb[pos[b] (+1 when advancing)] — the

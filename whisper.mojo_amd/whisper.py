@@ -238,6 +238,11 @@ class Whisper:
         self.last_tokens, self.last_counts = toks, n
         return [toks[b, :n[b]].tolist() for b in range(B)]
 
+    def loop_steps(self, slot: int = 0) -> int:
+        """Loop iterations (whisper.mojo:205) enqueued for the slot's most recent completed pass: max_loop unless the early exit
+        (every utterance emitted eot, whisper.mojo:206-207) cut the loop.  Slot 0 also serves transcribe_batch."""
+        return int(_lib.lib().wm_transcribe_steps(self._h, slot))
+
     def transcribe(self, mel) -> List[int]:
         """whisper.mojo:184-223: mel [80, 3000] -> token ids."""
         return self.transcribe_batch(mel)[0]
