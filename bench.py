@@ -124,7 +124,7 @@ def pmc_traffic(workload):
 class Bench:
     """One loaded model + its shard of synthetic mels, with the timing legs."""
 
-    def __init__(self, workload, batch, rank, world, local, weights_cache):
+    def __init__(self, workload, batch, rank, world, local, weights_cache, coalesce=0):
         import ctypes as C
         import torch
         from whisper_mojo_amd import DT_BF16, DT_F16, DT_F32, WhisperConfig, _lib, dist as wdist
@@ -145,8 +145,9 @@ class Bench:
             self.L.wm_synth_weights(C.byref(dims), 0, w.ctypes.data_as(C.POINTER(C.c_float)))
             weights_cache[cfg_name] = w
         self.weights = weights_cache[cfg_name]
+        self.coalesce = coalesce
         self.model = Whisper(self.cfg, compute_dtype=DT[self.cdt], kv_dtype=DT[self.kdt], max_batch=self.B, device=local,
-                             decoder_fp32=workload in DECODER_FP32)
+                             decoder_fp32=workload in DECODER_FP32, coalesce=coalesce)
         self.model.load(WeightLoader.from_array(self.weights))
         # this rank's shard of the global batch: utterance u uses mel seed 1000+u
         self.total = self.B * world
@@ -169,15 +170,16 @@ class Bench:
             self.torch.distributed.barrier()
             self.torch.cuda.synchronize()
 
-    def run_steps(self, n, depth, max_loop=DECODE_STEPS, ignore_eot=True, mel=None, gather=True):
+    def run_steps(self, n, depth, max_loop=DECODE_STEPS, ignore_eot=True, mel=None, gather=True, eot=None):
         """n full passes, `depth` of them in flight through the library's pipeline slots (depth 1: wm_transcribe, synchronous).
         Every pass does the full work; all n are complete (ids on the host, gathered) when this returns."""
         m, mel = self.model, (self.mel_dev if mel is None else mel)
         stride = 4 + 1 + max_loop
         out = None
+        kw = {} if eot is None else {"eot": eot}
         if depth <= 1:
             for _ in range(n):
-                m.transcribe_batch(mel, max_loop=max_loop, ignore_eot=ignore_eot)
+                m.transcribe_batch(mel, max_loop=max_loop, ignore_eot=ignore_eot, **kw)
                 self.last_counts = [m.last_counts]
                 if gather:
                     out = self.wdist.gather_tokens(m.last_tokens, m.last_counts, self.total, stride)
@@ -189,7 +191,7 @@ class Bench:
         while k < n:
             g = min(depth, n - k)
             for sl in range(g):
-                m.transcribe_submit(mel, slot=sl, max_loop=max_loop, ignore_eot=ignore_eot)
+                m.transcribe_submit(mel, slot=sl, max_loop=max_loop, ignore_eot=ignore_eot, **kw)
             done = []
             for sl in range(g):
                 m.transcribe_wait(sl)
@@ -314,14 +316,18 @@ def ladder_entry(name, rank, world, local, weights_cache, depth):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)  # a multiple of the pipeline depth: passes complete in groups of four
+    ap.add_argument("--steps", type=int, default=16)  # a multiple of the pipeline depth: passes complete in groups of eight (four uncoalesced)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-x4", action="store_true", help="skip the four-chains-in-flight decode step timing (profiler runs: keeps every launch of the dominant kernel alone on the chip)")
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after another")
-    ap.add_argument("--pipeline", type=int, default=4, choices=[1, 2, 3, 4, 5, 6, 7, 8], help="steps in flight (library pipeline slots)")
+    ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 7, 8],
+                    help="steps in flight (library pipeline slots); 0 = 8 with --coalesce 2 (four 128-row passes), else 4")
+    ap.add_argument("--coalesce", type=int, default=2, choices=[0, 2],
+                    help="2: the library pairs consecutive 64-clip submits into one 128-row decode state (wm_config.coalesce); every "
+                         "submit still is B = 64 and gets its own ids.  0: one decode state per submit")
     ap.add_argument("--no-extras", action="store_true", help="skip the value_with_h2d / natural / precision_ladder legs (profiler and test runs)")
     ap.add_argument("--dump-ids", default="", help="rank 0 writes the gathered ids of the last timed step to this .npy file (tests)")
     args = ap.parse_args()
@@ -337,10 +343,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
-    depth = 1 if args.no_pipeline else args.pipeline
+    if args.no_pipeline:
+        args.coalesce = 0
+    depth = 1 if args.no_pipeline else (args.pipeline or (8 if args.coalesce == 2 else 4))
     weights_cache = {}
     log("generating weights, loading model, synthesising mels")
-    b = Bench(args.workload, args.batch, rank, world, local, weights_cache)
+    b = Bench(args.workload, args.batch, rank, world, local, weights_cache, coalesce=args.coalesce)
     stride = 4 + 1 + DECODE_STEPS
 
     log("set-up of the pipeline slots; warm-up")
@@ -382,6 +390,22 @@ def main():
                              "generated_ids_per_utterance": round(gen, 1), "tokens_per_sec": round(b.total * gen * nat_n / n_dt, 1),
                              "synchronous_ms_per_step": round(s_dt / 2 * 1e3, 3),
                              "note": "random-init weights almost never emit eot: natural mode runs to the 195-iteration bound"}
+        # the same stop rule with an eot every utterance reaches: 64 copies of clip 0, eot := the id it emits at iteration 60 — the
+        # loop is cut there (whisper.mojo:206-207), at most two sub-chunks of 8 steps late
+        import torch
+        same = b.mel_dev[:1].expand(b.count, -1, -1).contiguous()
+        free = b.model.transcribe_batch(same[:1], max_loop=NATURAL_LOOP, ignore_eot=True)[0]
+        eot = int(free[4 + 60])
+        stop = free.index(eot, 4) - 4  # loop iterations until the first occurrence
+        b.run_steps(min(depth, 2), depth, max_loop=NATURAL_LOOP, ignore_eot=False, mel=same, eot=eot, gather=False)
+        r_dt, _ = b.timed(nat_n, depth, max_loop=NATURAL_LOOP, ignore_eot=False, mel=same, eot=eot, gather=False)
+        steps_run = b.model.loop_steps(0)
+        b.run_steps(1, 1, max_loop=NATURAL_LOOP, ignore_eot=False, mel=same, eot=eot, gather=False)
+        rs_dt, _ = b.timed(2, 1, max_loop=NATURAL_LOOP, ignore_eot=False, mel=same, eot=eot, gather=False)
+        extras["natural_reachable_eot"] = {"what": "64 copies of clip 0, eot := the id it emits at loop iteration 60", "eot_at_iteration": stop,
+                                           "loop_iterations_enqueued": steps_run, "steps": nat_n, "ms_per_step": round(r_dt / nat_n * 1e3, 3),
+                                           "synchronous_ms_per_step": round(rs_dt / 2 * 1e3, 3), "synchronous_loop_iterations": b.model.loop_steps(0)}
+        del same, torch
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         rtf, tok_s = b.rates(dt, args.steps, DECODE_STEPS + 1)
@@ -397,7 +421,10 @@ def main():
                                    f"1 prefill + {DECODE_STEPS} decode steps; {prec}; accumulation / LayerNorm / softmax / residual fp32; "
                                    "random-init weights (seed 0)",
                        "name": args.workload, "utterances_per_gpu": b.B, "kv_dtype": b.kdt, "parallelism": f"dp{world}",
-                       "pipeline_depth": depth},
+                       "pipeline_depth": depth,
+                       "coalesce": ("the library pairs consecutive 64-clip submits into one 128-row decode state (wm_config.coalesce = 2): "
+                                    f"{depth} submits in flight = {depth // 2} passes of 128 rows; every submit is B = 64 and receives its own ids, "
+                                    "bit-identical to the uncoalesced run (tests/test_gpu_edges.py)") if args.coalesce == 2 else "off"},
         }
         in_pass = extras.pop("_in_pass_step_us", None)
         res.update(extras)
@@ -408,6 +435,18 @@ def main():
             res["decode_step"]["in_pass_avg_us"] = round(in_pass, 1)
             res["decode_step"]["in_pass_frac_of_hbm_peak"] = round(sb / (in_pass * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         if world == 1 and not args.no_extras:
+            if args.coalesce == 2:  # the same workload with one decode state per submit, four in flight (round 2's protocol)
+                log("uncoalesced comparison")
+                b.model.close()
+                u = Bench(args.workload, args.batch, rank, world, local, weights_cache, coalesce=0)
+                try:
+                    u.setup_slots(4)
+                    u.run_steps(4, 4)
+                    u_dt, _ = u.timed(12, 4)
+                    res["value_uncoalesced"] = {"value": round(u.rates(u_dt, 12, 1)[0], 1), "ms_per_step": round(u_dt / 12 * 1e3, 3), "steps": 12,
+                                                "pipeline_depth": 4, "ratio": round(res["value"] / u.rates(u_dt, 12, 1)[0], 4)}
+                finally:
+                    u.close()
             res["precision_ladder"] = []
             for name in LADDER:
                 if name == args.workload:

@@ -39,6 +39,12 @@ typedef struct {
     int decoder_fp32;  /* != 0: compute_dtype applies to the ENCODER only (conv stem, encoder blocks, cross-K/V projection); the
                           decoder's weights and MFMA operands stay fp32 — BASELINE config 3 read literally ("bf16 encoder GEMMs").
                           0 (a zero-filled tail): one dtype for both, as before */
+    int coalesce;      /* 2: two consecutive wm_transcribe_submit calls with the same batch size and options share ONE decode state of
+                          2·B rows (the latency-bound launches of a decode step cost the same for 128 rows as for 64): the first call of
+                          a pair is held until its partner arrives — or until it is waited for, then it runs alone — and every call
+                          still gets exactly its own ids, bit-identical to an uncoalesced run (nothing in an utterance's arithmetic
+                          depends on the batch it rides in).  A host-side mel buffer must then stay valid until the matching wait.
+                          0 / 1: off */
 } wm_config;
 
 /* Replaces the literals in Whisper.transcribe (whisper.mojo:187-191 prompt, :206 eot, :205 loop bound). */
@@ -76,7 +82,7 @@ const char* wm_last_error(void);
  * built against an older header would hand the library structs whose tail it never wrote.  WM_ABI_VERSION is bumped with every
  * such change; a host binding compares it with wm_abi_version() once after loading the library and refuses a mismatch (the
  * Python and C++ mirrors do). */
-#define WM_ABI_VERSION 3
+#define WM_ABI_VERSION 4
 int wm_abi_version(void);
 
 /* ---- WeightLoader(filename) + Whisper() + Whisper.load(loader)   loader.mojo:10-27, whisper.mojo:175-182 ----

@@ -180,3 +180,72 @@ def test_block_prefill_equals_stepwise(hip, micro_cfg, micro_weights, q_len):
     na = m.decoder.forward(toks[:, q_len:], None, ca, start_pos=q_len)
     nb = m.decoder.forward(toks[:, q_len:], None, cb, start_pos=q_len)
     assert np.array_equal(na, nb)
+
+
+# ------------------------------------------------------------------------------------------------ coalesced submits
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_coalesced_submits_return_each_batch_its_own_ids(hip, micro_cfg, micro_weights, dtype):
+    """wm_config.coalesce = 2: two consecutive wm_transcribe_submit calls share one 2·B-row decode state.  Every call must
+    still return exactly what it returns uncoalesced (bit for bit: nothing in an utterance's arithmetic depends on the batch
+    it rides in), whatever the pairing: pairs, a leftover that runs alone at its wait, waits in reverse order, a partner
+    whose options differ (no pairing), the reference's stop rule with different stop points in the two halves."""
+    from whisper_mojo_amd import _lib, synth
+    B = 3
+    mels = [synth.synth_mels(micro_cfg, 10 * k, B) for k in range(5)]
+    kw = dict(prompt=(1, 2, 3, 4), eot=-1, max_loop=20)
+    plain = make_model(micro_cfg, micro_weights, compute_dtype=dtype, max_batch=B)
+    want = [plain.transcribe_batch(x, **kw) for x in mels]
+    m = make_model(micro_cfg, micro_weights, compute_dtype=dtype, max_batch=B, coalesce=2)
+    # two pairs + a leftover, collected in submit order
+    for k in range(5):
+        m.transcribe_submit(mels[k], slot=k, **kw)
+    assert [m.transcribe_wait(k) for k in range(5)] == want
+    # collected in reverse order; slot numbers unrelated to the pairing
+    for k, slot in enumerate((6, 2, 7, 0)):
+        m.transcribe_submit(mels[k], slot=slot, **kw)
+    got = {slot: m.transcribe_wait(slot) for slot in (0, 7, 2, 6)}
+    assert [got[6], got[2], got[7], got[0]] == want[:4]
+    # a partner with other options is not paired: both run alone, both right
+    kw2 = dict(kw, max_loop=12)
+    want2 = plain.transcribe_batch(mels[1], **kw2)
+    m.transcribe_submit(mels[0], slot=0, **kw)
+    m.transcribe_submit(mels[1], slot=1, **kw2)
+    assert m.transcribe_wait(1) == want2 and m.transcribe_wait(0) == want[0]
+    # a busy slot is refused while its batch is only held, too
+    m.transcribe_submit(mels[0], slot=3, **kw)
+    with pytest.raises(_lib.WhisperMiError, match="not waited"):
+        m.transcribe_submit(mels[1], slot=3, **kw)
+    # the synchronous call flushes the held batch first and is unaffected by it
+    assert m.transcribe_batch(mels[2], **kw) == want[2]
+    assert m.transcribe_wait(3) == want[0]
+    # the reference's stop rule: halves that stop at different iterations (the pair runs until BOTH are done)
+    free = want[0][0]
+    eot = free[4 + 6]
+    kw3 = dict(prompt=(1, 2, 3, 4), eot=eot, max_loop=40)
+    w0, w1 = plain.transcribe_batch(mels[0], **kw3), plain.transcribe_batch(mels[1], **kw3)
+    m.transcribe_submit(mels[0], slot=0, **kw3)
+    m.transcribe_submit(mels[1], slot=1, **kw3)
+    assert m.transcribe_wait(0) == w0 and m.transcribe_wait(1) == w1
+    m.close()
+    plain.close()
+
+
+def test_coalesced_tiny_b64_pairs_equal_uncoalesced(hip, tiny_cfg, tiny_weights):
+    """The benched form: BASELINE config 3 as written (bf16 encoder, fp32 decoder + KV), 64 clips per submit, coalesce = 2, four
+    submits in flight = two 128-row passes.  Each submit's ids equal the uncoalesced model's, bit for bit, all 64 rows."""
+    import ctypes as C
+    from whisper_mojo_amd import _lib
+    L = _lib.lib()
+    mels = np.empty((128, 80, 3000), np.float32)
+    for i in range(128):
+        L.wm_synth_mel_host(1000 + i, 80, 3000, mels[i].ctypes.data_as(C.POINTER(C.c_float)))
+    kw = dict(max_loop=30, ignore_eot=True)
+    plain = make_model(tiny_cfg, tiny_weights, compute_dtype=1, kv_dtype=0, max_batch=64, decoder_fp32=True)
+    want = [plain.transcribe_batch(mels[:64], **kw), plain.transcribe_batch(mels[64:], **kw)]
+    plain.close()
+    m = make_model(tiny_cfg, tiny_weights, compute_dtype=1, kv_dtype=0, max_batch=64, decoder_fp32=True, coalesce=2)
+    for slot, half in ((0, 0), (1, 1), (2, 1), (3, 0)):
+        m.transcribe_submit(mels[64 * half:64 * half + 64], slot=slot, **kw)
+    assert m.transcribe_wait(0) == want[0] and m.transcribe_wait(1) == want[1]
+    assert m.transcribe_wait(2) == want[1] and m.transcribe_wait(3) == want[0]
+    m.close()

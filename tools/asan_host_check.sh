@@ -8,24 +8,54 @@ set -euo pipefail
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 EXE="$ROOT/examples/whisper_main_asan"
 CSRC="$ROOT/whisper.mojo_amd/csrc"
+PROBE="$ROOT/tools/micro/asan_exit_probe"
+SANFLAGS="-Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-omit-frame-pointer"
 if [ "${1:-build}" = build ]; then
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -Wall -Wno-unused-function -ffp-contract=on \
-    -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-omit-frame-pointer \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -Wall -Wno-unused-function -ffp-contract=on $SANFLAGS \
     -I "$ROOT/include" -x hip "$CSRC/whisper_mi.cpp" "$CSRC/kernels_encoder.hip" "$CSRC/kernels_decoder.hip" "$CSRC/kernels_frontend.hip" \
     -x hip "$ROOT/examples/main.cpp" -o "$EXE"
-  echo "built $EXE"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 $SANFLAGS -x hip "$ROOT/tools/micro/asan_exit_probe.hip" -o "$PROBE"
+  echo "built $EXE and $PROBE"
 else
   export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
-  # A run is judged by its report, not its exit code: at process exit the HSA runtime's own teardown (__cxa_finalize ->
-  # libhsa-runtime64 -> operator delete) sometimes trips an internal CHECK of the sanitizer's device allocator
-  # ("dev_runtime_unloaded_") after main() has returned and "Done." is printed — not this library's code.
+  # The one report this script may tolerate — and only if a BARE HIP program (tools/micro/asan_exit_probe.hip: no code of this
+  # repository) shows it too on this box: the sanitizer's own device allocator CHECK at process exit,
+  #   AddressSanitizer: CHECK failed: sanitizer_allocator_device.h:<n> "((!dev_runtime_unloaded_)) != (0)"
+  # raised while the sanitizer recycles its quarantine after main has returned ("Done." printed) — from __cxa_finalize ->
+  # libamdhip64 -> libhsa-runtime64 -> operator delete, or from an exiting thread's AsanThread::Destroy -> CommitBack: the
+  # quarantine then still holds freed DEVICE chunks (under host ASan every hipMalloc is a chunk of the sanitizer's device
+  # allocator), and recycling one after the HSA runtime has unloaded trips the CHECK (probe modes 3 / 4 say which pattern does).
+  SIG='AddressSanitizer: CHECK failed: sanitizer_allocator_device.h:[0-9]* "((!dev_runtime_unloaded_)) != (0)"'
+  probe_sig=0
+  for mode in 0 1 2 3 4; do
+    log=$(mktemp); rc=0
+    "$PROBE" $mode > "$log" 2>&1 || rc=$?
+    if grep -q "$SIG" "$log"; then probe_sig=1; echo "[probe mode $mode] exit $rc: shows the exit-time device-allocator CHECK (bare HIP program)";
+    else echo "[probe mode $mode] exit $rc: no sanitizer report"; fi
+    grep -q "^Done\.$" "$log" || { echo "probe mode $mode did not finish"; cat "$log"; exit 1; }
+    if [ $rc -ne 0 ] && ! grep -q "$SIG" "$log"; then echo "probe mode $mode failed for another reason"; cat "$log"; exit 1; fi
+  done
   run() {
-    local log; log=$(mktemp)
-    "$EXE" "$@" > "$log" 2>&1 || true
+    local log rc=0; log=$(mktemp)
+    "$EXE" "$@" > "$log" 2>&1 || rc=$?
     cat "$log"
-    if grep -q "ERROR: AddressSanitizer\|runtime error:\|SUMMARY: .*Sanitizer" "$log" || ! grep -q "^Done\.$" "$log"; then
-      echo "ASAN/UBSAN host check: FAILED ($*)"; exit 1
+    local bad=0
+    grep -q "ERROR: AddressSanitizer\|runtime error:\|SUMMARY: .*Sanitizer" "$log" && bad=1
+    grep -q "^Done\.$" "$log" || bad=1
+    if grep -q "AddressSanitizer: CHECK failed" "$log"; then
+      # tolerated only as the probe's signature, once, after "Done.", with __cxa_finalize and no frame of this executable's own code above it
+      if [ $probe_sig -eq 1 ] && [ "$(grep -c 'AddressSanitizer: CHECK failed' "$log")" = 1 ] && grep -q "$SIG" "$log" && \
+         [ "$(grep -n '^Done\.$' "$log" | cut -d: -f1)" -lt "$(grep -n 'CHECK failed' "$log" | cut -d: -f1)" ] && \
+         grep -q "Quarantine.*Recycle" "$log" && grep -q "__cxa_finalize\|AsanThread::Destroy" "$log" && \
+         ! grep -q "whisper_mi.cpp\|kernels_.*\.hip\|main.cpp" "$log"; then
+        echo "[tolerated] exit-time device-allocator CHECK of the sanitizer runtime (the bare probe shows it too); exit code $rc"
+      else
+        bad=1
+      fi
+    elif [ $rc -ne 0 ]; then
+      bad=1  # a non-zero exit without that signature is a failure
     fi
+    if [ $bad -ne 0 ]; then echo "ASAN/UBSAN host check: FAILED ($*) exit $rc"; exit 1; fi
   }
   for dt in f32 bf16; do
     run --config micro --synthetic-weights 0 --synthetic-mel 1000 --dtype $dt --prompt 1,2,3,4 --eot 532 --max-loop 40 --vocab /nonexistent

@@ -21,13 +21,13 @@ SYMBOLS = [
     "wm_op_argmax", "wm_bench_kernel", "wm_bench_bytes", "wm_synth_weights", "wm_synth_mel_host",
 ]
 
-ABI_VERSION = 3  # include/whisper_mi.h WM_ABI_VERSION: the struct layouts below are this version's
+ABI_VERSION = 4  # include/whisper_mi.h WM_ABI_VERSION: the struct layouts below are this version's
 KERNEL_CROSS_ATTN, KERNEL_DECODE_STEP, KERNEL_ENCODER, KERNEL_DECODE_STEP_SHARED = 0, 1, 2, 3
 
 
 class WmConfig(C.Structure):
     _fields_ = [("dims", WmDims), ("gelu_mode", C.c_int), ("compute_dtype", C.c_int), ("kv_dtype", C.c_int),
-                ("max_batch", C.c_int), ("decoder_fp32", C.c_int)]
+                ("max_batch", C.c_int), ("decoder_fp32", C.c_int), ("coalesce", C.c_int)]
 
 
 class WmDecodeOpts(C.Structure):

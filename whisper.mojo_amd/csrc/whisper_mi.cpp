@@ -202,6 +202,24 @@ struct wm_model {
     wm_state* cached = nullptr;           // slot 0: the state behind wm_transcribe / wm_transcribe_submit(slot 0)
     wm_state* slots[NSLOT - 1] = {};  // slots 1..7: further pipeline stages (wm_transcribe_submit)
     std::unordered_set<wm_state*> states;  // every state created on this model (wm_state_new), freed with it
+    // Coalescing (wm_config.coalesce == 2): two consecutive wm_transcribe_submit calls of the same batch size and options share ONE
+    // decode state of 2·B rows — the 33 latency-bound launches of a decode step cost the same for 128 rows as for 64.  The first
+    // call of a pair is held (`held`) until its partner arrives (or until it is waited for: then it runs alone); each call still
+    // returns exactly its own ids.
+    struct Held {
+        bool active = false;
+        int slot = 0, B = 0, on_dev = 0;
+        const float* mel = nullptr;
+        wm_decode_opts o{};
+        std::vector<int32_t> prompt, sup, bsup;  // deep copies: the caller's option arrays need not outlive the call
+    } held;
+    struct SlotRef {  // where a submitted slot's rows live
+        bool pending = false;
+        wm_state* st = nullptr;  // null while the slot is only held
+        int row0 = 0, rows = 0, total = 0;
+    } slot_ref[8];
+    wm_state* pairs[4] = {};  // 2·B-row states of coalesced pairs
+    int last_steps[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // loop iterations enqueued for each slot's last collected pass
     // Loop pump (natural-stop passes of wm_transcribe_submit): one host thread per model that keeps each pending pass's greedy loop
     // two sub-chunks ahead of the GPU and stops enqueueing once the device reports every utterance finished (whisper.mojo:206-207).
     std::thread pump;
@@ -236,6 +254,8 @@ struct wm_state {
     int graph_eot = 0, graph_ignore = 0;
     bool graphs_valid = false;
     bool pending = false;   // a submitted pass has not been waited for yet
+    int halves_left = 0;    // coalesced pair: slots that have not collected their rows yet
+    bool synced = false;    // the pending pass's completion has been waited for (second half of a pair does not wait again)
     bool shares_chip = false;  // this state's passes run beside other passes (pipelined entry): K/V stream at two workgroups per CU
     bool graph_shares = false;
     int trace_id = 1;       // slot + 1: tags this state's entries in the developer timeline
@@ -340,6 +360,7 @@ static int check_cfg(const wm_config* c) {
     if (!(c->kv_dtype == WM_F32 || c->kv_dtype == c->compute_dtype))
         return fail(WM_E_ARG, "kv_dtype must be WM_F32 or equal compute_dtype");
     if (c->decoder_fp32 != 0 && c->decoder_fp32 != 1) return fail(WM_E_ARG, "decoder_fp32 must be 0 or 1");
+    if (c->coalesce < 0 || c->coalesce > 2) return fail(WM_E_ARG, "coalesce must be 0, 1 (both: off) or 2");
     if (c->max_batch <= 0) return fail(WM_E_ARG, "max_batch must be > 0");
     if (c->gelu_mode != 0 && c->gelu_mode != 1) return fail(WM_E_ARG, "bad gelu_mode");
     return 0;
@@ -718,6 +739,10 @@ extern "C" void wm_state_free(wm_state* s) {
     if (s->m->cached == s) s->m->cached = nullptr;
     for (auto& sl : s->m->slots)
         if (sl == s) sl = nullptr;
+    for (auto& pr : s->m->pairs)
+        if (pr == s) pr = nullptr;
+    for (auto& r : s->m->slot_ref)
+        if (r.st == s) r = wm_model::SlotRef{};
     (void)hipSetDevice(s->m->device);
     // nothing of this state may still be running when its graphs, streams and arenas go away (a submitted pass that was
     // never waited for, or the model stream's last wm_decode_step)
@@ -744,9 +769,12 @@ extern "C" void wm_state_free(wm_state* s) {
 
 static const int OUT_STRIDE_MAX = 1024;
 
-extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
+static int state_new(wm_model* m, int B, wm_state** out, bool pair);
+extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) { return state_new(m, B, out, false); }
+// pair: the 2·B-row state of a coalesced pair of submits (B <= max_batch each)
+static int state_new(wm_model* m, int B, wm_state** out, bool pair) {
     if (!m || !out || B <= 0) return fail(WM_E_ARG, "bad argument");
-    if (B > m->cfg.max_batch) return fail(WM_E_ARG, "batch %d exceeds max_batch %d", B, m->cfg.max_batch);
+    if (B > m->cfg.max_batch * (pair ? 2 : 1)) return fail(WM_E_ARG, "batch %d exceeds max_batch %d", B, m->cfg.max_batch);
     HIPCHK(hipSetDevice(m->device));
     const wm_dims& c = m->cfg.dims;
     const size_t d = c.d_model, L = 2 * (size_t)c.n_audio_ctx, T = c.n_audio_ctx;
@@ -759,7 +787,7 @@ extern "C" int wm_state_new(wm_model* m, int B, wm_state** out) {
         g_live_states.insert(s);
     }
     m->states.insert(s);
-    s->Bc = std::min(B, m->enc_chunk);
+    s->Bc = std::min(pair ? B / 2 : B, m->enc_chunk);  // (pair: an encoder chunk never straddles the two batches)
     // key chunks per utterance for the cross-attention kernel: a function of the MODEL's max_batch, never of this call's
     // B, so that an utterance's result does not depend on how it was batched (bitwise batch invariance within a model).
     // Aim for 1024 workgroups at full batch (4 per CU, one full round): 16 chunks at max_batch 64 (measured, µs per launch /
@@ -909,7 +937,8 @@ static int cross_kv_chunk(wm_model* m, wm_state* s, int c0, int bc, hipStream_t 
     return gemm_dispatch(m->cfg.compute_dtype, m->cfg.kv_dtype, p, 1, st);
 }
 
-static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hipStream_t st) {
+// mel2 / split_at (coalesced pairs): utterances [split_at, B) come from mel2 (their own batch's buffer); split_at is a multiple of Bc
+static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hipStream_t st, const float* mel2 = nullptr, int split_at = 0) {
     const wm_dims& c = m->cfg.dims;
     const int T = m->cfg.compute_dtype;
     const size_t d = c.d_model, L = 2 * (size_t)c.n_audio_ctx, NT = c.n_audio_ctx, ts = dt_size(T);
@@ -919,7 +948,8 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
         const int M = (int)(bc * NT);
         const int opb = T == WM_F32 ? 4 : 2;
         bool xn_is_ln1 = false;  // xn holds LN1(x) of the coming block, written by the epilogue of the GEMM that produced x
-        DISPATCH_DT(T, TT, launch_mel_transpose_pad<TT>(mel_dev + (size_t)c0 * c.n_mels * L, s->mel_t.p, bc, c.n_mels, (int)L, m->Cp, st));
+        const float* mel_c = (mel2 && c0 >= split_at) ? mel2 + (size_t)(c0 - split_at) * c.n_mels * L : mel_dev + (size_t)c0 * c.n_mels * L;
+        DISPATCH_DT(T, TT, launch_mel_transpose_pad<TT>(mel_c, s->mel_t.p, bc, c.n_mels, (int)L, m->Cp, st));
         {  // conv1 + GELU -> h1 rows 1..L (token-major)   whisper.mojo:73-75
             GemmParams p{};
             p.A = s->mel_t.p;
@@ -1660,19 +1690,23 @@ static int check_opts(wm_model* m, const wm_decode_opts* o, int B) {
     return 0;
 }
 
-static int submit_on(wm_model* m, wm_state** slot, const float* mel, int mel_on_device, int B, const wm_decode_opts* o, bool allow_poll) {
+// Enqueues one whole pass (encoder, prefill, greedy loop) for B utterances on state *slot (created / re-created on demand).
+// mel2 != null: a coalesced pair — *slot is a 2·(B/2)-row pair state, utterances [B/2, B) come from mel2.
+static int submit_on(wm_model* m, wm_state** slot, const float* mel, int mel_on_device, int B, const wm_decode_opts* o, bool allow_poll,
+                     const float* mel2 = nullptr, int mel2_on_device = 0) {
     const wm_dims& c = m->cfg.dims;
     HIPCHK(hipSetDevice(m->device));
+    const bool pair = mel2 != nullptr;
     // a pass that was submitted and not yet waited for owns the slot's state: refuse BEFORE touching it (re-creating the
     // state for another batch size would destroy graphs, streams and arenas under its running kernels)
     if (*slot && (*slot)->pending) return fail(WM_E_STATE, "this slot still holds a pass that was not waited for");
     if (!*slot || (*slot)->B != B) {
         if (*slot) wm_state_free(*slot);
         *slot = nullptr;
-        WMCHK(wm_state_new(m, B, slot));
+        WMCHK(state_new(m, B, slot, pair));
     }
     wm_state* s = *slot;
-    s->trace_id = slot == &m->cached ? 1 : 2 + (int)(slot - m->slots);
+    s->trace_id = slot == &m->cached ? 1 : (slot >= m->slots && slot < m->slots + wm_model::NSLOT - 1) ? 2 + (int)(slot - m->slots) : 10 + (int)(slot - m->pairs);
     // The whole pass — encoder, prefill, greedy loop — goes on the slot's own stream: four slots are then four hardware
     // queues, which is what the chip runs concurrently (a fifth queue, e.g. a shared encoder stream, lands on a pipe that
     // already serves one of them and the two take turns: 22.3 vs 20.8 ms per pass at four passes in flight).
@@ -1685,18 +1719,26 @@ static int submit_on(wm_model* m, wm_state** slot, const float* mel, int mel_on_
         HIPCHK(hipEventRecord(s->enc_done, m->stream));
         HIPCHK(hipStreamWaitEvent(est, s->enc_done, 0));
     }
+    const size_t mel_floats = (size_t)c.n_mels * 2 * c.n_audio_ctx;  // per utterance
+    const int B1 = pair ? B / 2 : B;
     const float* mel_dev = mel;
     if (!mel_on_device) {
-        HIPCHK(hipMemcpyAsync(s->mel_dev.p, mel, (size_t)B * c.n_mels * 2 * c.n_audio_ctx * 4, hipMemcpyHostToDevice, est));
+        HIPCHK(hipMemcpyAsync(s->mel_dev.p, mel, (size_t)B1 * mel_floats * 4, hipMemcpyHostToDevice, est));
         mel_dev = s->mel_dev.as<float>();
+    }
+    const float* mel2_dev = mel2;
+    if (pair && !mel2_on_device) {
+        float* dst = s->mel_dev.as<float>() + (size_t)B1 * mel_floats;
+        HIPCHK(hipMemcpyAsync(dst, mel2, (size_t)B1 * mel_floats * 4, hipMemcpyHostToDevice, est));
+        mel2_dev = dst;
     }
     const auto tt0 = std::chrono::steady_clock::now();
     trace_mark(est, "state %p encoder start", (void*)s);
-    WMCHK(run_encoder(m, s, mel_dev, B, est));
+    WMCHK(run_encoder(m, s, mel_dev, B, est, mel2_dev, B1));
     trace_mark(est, "state %p encoder end", (void*)s);
     s->enc_stream = est;
     s->has_enc = s->has_cross = true;
-    s->last_mel = mel_dev;
+    s->last_mel = pair ? nullptr : mel_dev;
     if (wm_env("WM_TRACE_HOST")) {
         const auto tt1 = std::chrono::steady_clock::now();
         (void)hipStreamSynchronize(m->stream);
@@ -1705,29 +1747,87 @@ static int submit_on(wm_model* m, wm_state** slot, const float* mel, int mel_on_
     }
     WMCHK(transcribe_decode(m, s, o, allow_poll));
     s->pending = true;
+    s->synced = false;
+    s->halves_left = pair ? 2 : 1;
     s->pend_total = o->n_prompt + 1 + o->max_loop;
     s->host_len = 0;
     return 0;
 }
 
-static int wait_on(wm_model* m, wm_state* s, int32_t* tokens_out, int32_t* n_tokens) {
+// Blocks until the state's pending pass is complete, then copies `rows` utterances starting at row0 out.  The pass stays pending
+// until every slot that shares the state (one, or the two of a coalesced pair) has collected its rows.
+static int wait_on(wm_model* m, wm_state* s, int32_t* tokens_out, int32_t* n_tokens, int row0 = 0, int rows = -1) {
     if (!s || !s->pending) return fail(WM_E_STATE, "nothing was submitted on this slot");
     HIPCHK(hipSetDevice(m->device));
-    if (!s->enq_done.load()) {  // the loop pump is still feeding this pass
-        std::unique_lock<std::mutex> lk(m->pump_mu);
-        m->pump_cv.wait(lk, [&] { return s->enq_done.load(); });
+    if (rows < 0) rows = s->B;
+    if (!s->synced) {
+        if (!s->enq_done.load()) {  // the loop pump is still feeding this pass
+            std::unique_lock<std::mutex> lk(m->pump_mu);
+            m->pump_cv.wait(lk, [&] { return s->enq_done.load(); });
+        }
+        if (s->enq_rc) {
+            s->pending = false;
+            for (auto& ln : s->lanes) (void)hipStreamSynchronize(ln.st);
+            return fail(s->enq_rc, "%s", s->enq_err.c_str());
+        }
+        for (auto& ln : s->lanes) HIPCHK(hipEventSynchronize(ln.done));
+        s->synced = true;
     }
-    if (s->enq_rc) {
-        s->pending = false;
-        for (auto& ln : s->lanes) (void)hipStreamSynchronize(ln.st);
-        return fail(s->enq_rc, "%s", s->enq_err.c_str());
-    }
-    for (auto& ln : s->lanes) HIPCHK(hipEventSynchronize(ln.done));
     const int total = s->pend_total;
-    HIPCHK(hipMemcpy2D(tokens_out, (size_t)total * 4, s->out_tokens.p, (size_t)s->out_stride * 4, (size_t)total * 4, s->B, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(n_tokens, s->n_tokens.p, (size_t)s->B * 4, hipMemcpyDeviceToHost));
-    s->pending = false;
-    s->has_enc = false;  // the KV cache now holds a finished decode: a new wm_encode is needed before wm_decode_step
+    HIPCHK(hipMemcpy2D(tokens_out, (size_t)total * 4, s->out_tokens.as<int>() + (size_t)row0 * s->out_stride, (size_t)s->out_stride * 4, (size_t)total * 4, rows,
+                       hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(n_tokens, s->n_tokens.as<int>() + row0, (size_t)rows * 4, hipMemcpyDeviceToHost));
+    if (--s->halves_left <= 0) {
+        s->pending = false;
+        s->has_enc = false;  // the KV cache now holds a finished decode: a new wm_encode is needed before wm_decode_step
+    }
+    return 0;
+}
+
+static wm_state** slot_state(wm_model* m, int slot) { return slot == 0 ? &m->cached : &m->slots[slot - 1]; }
+
+// ---- coalescing of consecutive submits (wm_config.coalesce == 2) ------------------------------------------------------------------
+static bool same_opts(const wm_model::Held& h, const wm_decode_opts* o) {
+    const wm_decode_opts& a = h.o;
+    if (a.n_prompt != o->n_prompt || a.eot != o->eot || a.max_loop != o->max_loop || a.pos_mode != o->pos_mode || a.ignore_eot != o->ignore_eot ||
+        a.n_suppress != (o->suppress_tokens ? o->n_suppress : 0) || a.n_begin_suppress != (o->begin_suppress_tokens ? o->n_begin_suppress : 0) ||
+        a.timestamp_begin != o->timestamp_begin || a.no_timestamps_token != o->no_timestamps_token ||
+        a.max_initial_timestamp_index != o->max_initial_timestamp_index)
+        return false;
+    return std::equal(h.prompt.begin(), h.prompt.end(), o->prompt) && std::equal(h.sup.begin(), h.sup.end(), o->suppress_tokens) &&
+           std::equal(h.bsup.begin(), h.bsup.end(), o->begin_suppress_tokens);
+}
+static void hold(wm_model* m, int slot, const float* mel, int on_dev, int B, const wm_decode_opts* o) {
+    wm_model::Held& h = m->held;
+    h.active = true;
+    h.slot = slot;
+    h.B = B;
+    h.on_dev = on_dev;
+    h.mel = mel;
+    h.prompt.assign(o->prompt, o->prompt + o->n_prompt);
+    h.sup.assign(o->suppress_tokens, o->suppress_tokens + (o->suppress_tokens ? o->n_suppress : 0));
+    h.bsup.assign(o->begin_suppress_tokens, o->begin_suppress_tokens + (o->begin_suppress_tokens ? o->n_begin_suppress : 0));
+    h.o = *o;
+    h.o.prompt = h.prompt.data();
+    h.o.suppress_tokens = h.sup.empty() ? nullptr : h.sup.data();
+    h.o.n_suppress = (int)h.sup.size();
+    h.o.begin_suppress_tokens = h.bsup.empty() ? nullptr : h.bsup.data();
+    h.o.n_begin_suppress = (int)h.bsup.size();
+    m->slot_ref[slot] = wm_model::SlotRef{true, nullptr, 0, B, o->n_prompt + 1 + o->max_loop};
+}
+// the held submit runs alone, on its own slot's state (no partner came, or the partner did not match)
+static int flush_held(wm_model* m) {
+    wm_model::Held& h = m->held;
+    if (!h.active) return 0;
+    h.active = false;
+    wm_model::SlotRef& r = m->slot_ref[h.slot];
+    const int rc = submit_on(m, slot_state(m, h.slot), h.mel, h.on_dev, h.B, &h.o, false);
+    if (rc) {
+        r = wm_model::SlotRef{};
+        return rc;
+    }
+    r.st = *slot_state(m, h.slot);
+    r.row0 = 0;
     return 0;
 }
 
@@ -1735,27 +1835,73 @@ extern "C" int wm_transcribe(wm_model* m, const float* mel, int mel_on_device, i
                              int32_t* tokens_out, int32_t* n_tokens) {
     if (!m || !mel || !tokens_out || !n_tokens) return fail(WM_E_ARG, "bad argument");
     WMCHK(check_opts(m, o, B));
+    WMCHK(flush_held(m));  // a held submit goes first: this call may use its mel buffers' stream order, and slot 0
+    if (m->slot_ref[0].pending) return fail(WM_E_STATE, "this slot still holds a pass that was not waited for");
     WMCHK(submit_on(m, &m->cached, mel, mel_on_device, B, o, true));
-    return wait_on(m, m->cached, tokens_out, n_tokens);
+    WMCHK(wait_on(m, m->cached, tokens_out, n_tokens));
+    m->last_steps[0] = m->cached->last_steps;
+    return 0;
 }
 
-// Pipelined form of Whisper.transcribe for back-to-back batches: submit enqueues encoder (model stream) and the greedy
-// loop (the slot's decode stream) and returns; wait blocks until that slot's tokens are ready.  With two slots the
-// MFMA-bound encoder of batch i+1 overlaps the latency/HBM-bound decode of batch i.
+// Pipelined form of Whisper.transcribe for back-to-back batches: submit enqueues the encoder and the greedy loop on the slot's
+// stream and returns; wait blocks until that slot's tokens are ready.
 extern "C" int wm_transcribe_submit(wm_model* m, int slot, const float* mel, int mel_on_device, int B, const wm_decode_opts* o) {
     if (!m || !mel || slot < 0 || slot >= wm_model::NSLOT) return fail(WM_E_ARG, "bad argument (slot must be 0..7)");
     WMCHK(check_opts(m, o, B));
-    return submit_on(m, slot == 0 ? &m->cached : &m->slots[slot - 1], mel, mel_on_device, B, o, false);
+    wm_model::SlotRef& r = m->slot_ref[slot];
+    if (r.pending) return fail(WM_E_STATE, "this slot still holds a pass that was not waited for");
+    const int total = o->n_prompt + 1 + o->max_loop;
+    const bool can_pair = m->cfg.coalesce == 2 && B <= m->cfg.max_batch && (B <= m->enc_chunk || B % m->enc_chunk == 0);
+    if (can_pair && m->held.active && m->held.B == B && same_opts(m->held, o)) {
+        // the partner of the held submit: both batches go out as ONE pass on a 2·B-row state
+        wm_state** ps = nullptr;
+        for (auto& pr : m->pairs)
+            if (pr && !pr->pending && pr->B == 2 * B) ps = &pr;
+        for (auto& pr : m->pairs)
+            if (!ps && !pr) ps = &pr;
+        for (auto& pr : m->pairs)
+            if (!ps && !pr->pending) ps = &pr;  // another batch size: re-created
+        if (ps) {
+            wm_model::Held& h = m->held;
+            h.active = false;
+            wm_model::SlotRef& r0 = m->slot_ref[h.slot];
+            const int rc = submit_on(m, ps, h.mel, h.on_dev, 2 * B, &h.o, false, mel, mel_on_device);
+            if (rc) {
+                r0 = wm_model::SlotRef{};
+                return rc;
+            }
+            r0.st = *ps;
+            r0.row0 = 0;
+            r = wm_model::SlotRef{true, *ps, B, B, total};
+            return 0;
+        }
+    }
+    WMCHK(flush_held(m));
+    if (can_pair) {  // wait for a partner (or for this slot's wm_transcribe_wait)
+        hold(m, slot, mel, mel_on_device, B, o);
+        return 0;
+    }
+    WMCHK(submit_on(m, slot_state(m, slot), mel, mel_on_device, B, o, false));
+    r = wm_model::SlotRef{true, *slot_state(m, slot), 0, B, total};
+    return 0;
 }
 extern "C" int wm_transcribe_wait(wm_model* m, int slot, int32_t* tokens_out, int32_t* n_tokens) {
     if (!m || !tokens_out || !n_tokens || slot < 0 || slot >= wm_model::NSLOT) return fail(WM_E_ARG, "bad argument");
-    return wait_on(m, slot == 0 ? m->cached : m->slots[slot - 1], tokens_out, n_tokens);
+    wm_model::SlotRef& r = m->slot_ref[slot];
+    if (!r.pending) return fail(WM_E_STATE, "nothing was submitted on this slot");
+    if (m->held.active && m->held.slot == slot) {  // no partner came: the held batch runs alone now
+        const int rc = flush_held(m);
+        if (rc) return rc;
+    }
+    wm_state* s = r.st;
+    const int rc = wait_on(m, s, tokens_out, n_tokens, r.row0, r.rows);
+    if (!rc) m->last_steps[slot] = s->last_steps;
+    r = wm_model::SlotRef{};
+    return rc;
 }
-
 extern "C" int wm_transcribe_steps(wm_model* m, int slot) {
     if (!m || slot < 0 || slot >= wm_model::NSLOT) return -1;
-    wm_state* s = slot == 0 ? m->cached : m->slots[slot - 1];
-    return (s && state_is_live(s)) ? s->last_steps : -1;
+    return m->last_steps[slot];
 }
 
 // ---- log-mel front end: 16 kHz PCM -> [n_mels, n_frames]  (export_weights.py:100-116 delegates this to
@@ -1869,8 +2015,12 @@ extern "C" int wm_transcribe_pcm(wm_model* m, const float* pcm, const int32_t* n
     if (!m || !tokens_out || !n_tokens) return fail(WM_E_ARG, "bad argument");
     WMCHK(check_opts(m, o, B));
     WMCHK(frontend_run(m, pcm, n_samples, B, stride));  // same stream as the encoder: ordered, no host sync
+    WMCHK(flush_held(m));
+    if (m->slot_ref[0].pending) return fail(WM_E_STATE, "this slot still holds a pass that was not waited for");
     WMCHK(submit_on(m, &m->cached, m->fe.mel.as<float>(), 1, B, o, true));
-    return wait_on(m, m->cached, tokens_out, n_tokens);
+    WMCHK(wait_on(m, m->cached, tokens_out, n_tokens));
+    m->last_steps[0] = m->cached->last_steps;
+    return 0;
 }
 
 // ---- measurement helpers ------------------------------------------------------------------------------------------------

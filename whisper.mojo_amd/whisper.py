@@ -137,7 +137,7 @@ class Whisper:
 
     def __init__(self, config: Optional[WhisperConfig] = None, compute_dtype: int = DT_F32, kv_dtype: Optional[int] = None,
                  gelu_mode: int = GELU_TANH, pos_mode: int = POS_REF, max_batch: int = 64, device: int = 0,
-                 decoder_fp32: bool = False):
+                 decoder_fp32: bool = False, coalesce: int = 0):
         self.config = config or WhisperConfig.tiny()
         self.compute_dtype = compute_dtype
         self.kv_dtype = compute_dtype if kv_dtype is None else kv_dtype
@@ -146,6 +146,7 @@ class Whisper:
         self.max_batch = max_batch
         self.device = device
         self.decoder_fp32 = decoder_fp32  # compute_dtype narrows the encoder only; decoder weights / operands stay fp32
+        self.coalesce = coalesce  # 2: consecutive transcribe_submit calls of equal batch size / options share one 2·B-row decode state
         self._h = None
         self._caches = weakref.WeakSet()  # live KVCaches of the loaded model
         self.encoder = WhisperEncoder(self)
@@ -153,7 +154,7 @@ class Whisper:
 
     def _cfg(self) -> _lib.WmConfig:
         return _lib.WmConfig(self.config.dims(), self.gelu_mode, self.compute_dtype, self.kv_dtype, self.max_batch,
-                             int(self.decoder_fp32))
+                             int(self.decoder_fp32), int(self.coalesce))
 
     def load(self, loader: WeightLoader):
         """whisper.mojo:180-182.  Raises if the image size does not match the config."""
