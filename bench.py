@@ -160,6 +160,11 @@ class Bench:
                                      self.mel_host[i].ctypes.data_as(C.POINTER(C.c_float)))
         self.mel_dev = self.mel_pinned.to(self.dev)  # resident in HBM before the timed region
         self.last_counts = []
+        # N > 1 over RCCL: the ids stay on the device as the gather buffer (wm_transcribe_wait_device) — no host round trip before
+        # the all-gather.  (gloo rehearsals and N = 1 take the host path; WM_BENCH_DEVICE_GATHER=1 forces the device path at N = 1.)
+        dg = os.environ.get("WM_BENCH_DEVICE_GATHER")
+        self.device_gather = bool(dg) or (world > 1 and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl")
+        self.rows_per_rank = (self.total + world - 1) // world
 
     def close(self):
         self.model.close()
@@ -193,6 +198,16 @@ class Bench:
             for sl in range(g):
                 m.transcribe_submit(mel, slot=sl, max_loop=max_loop, ignore_eot=ignore_eot, **kw)
             done = []
+            if gather and self.device_gather:
+                for sl in range(g):
+                    packed = self.torch.empty((self.rows_per_rank, 1 + stride), dtype=self.torch.int32, device=self.dev)
+                    m.transcribe_wait_device(sl, packed)
+                    done.append(packed)
+                for packed in done:
+                    out = self.wdist.gather_tokens_device(packed, self.total)
+                self.last_counts = [np.asarray([len(o) for o in out[self.first:self.first + self.count]], np.int32)]
+                k += g
+                continue
             for sl in range(g):
                 m.transcribe_wait(sl)
                 done.append((m.last_tokens, m.last_counts))
@@ -338,6 +353,12 @@ def main():
     # rehearsal knobs (not used by the driver): WM_BENCH_BACKEND=gloo + WM_BENCH_SINGLE_DEVICE=1 run N ranks on ONE GPU
     backend = os.environ.get("WM_BENCH_BACKEND", "nccl")
     rank, local, world = wdist.init_from_env(backend)
+    if os.environ.get("WM_BENCH_DEVICE_GATHER") and world == 1 and not torch.distributed.is_initialized():
+        # one-GPU rehearsal of the RCCL path: a world of one still initialises RCCL and runs the device-buffer gather code
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        torch.cuda.set_device(0)
+        torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1)
     if os.environ.get("WM_BENCH_SINGLE_DEVICE"):
         local = 0
     if world != args.gpus:
@@ -463,7 +484,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(b.cfg, b.weights, b.mel_host[0], DECODE_STEPS)
         print(json.dumps(res), flush=True)
     b.close()
-    if world > 1:
+    if world > 1 or torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -148,6 +148,11 @@ int wm_transcribe(wm_model* m, const float* mel, int mel_on_device, int B, const
  * is a device pointer. */
 int wm_transcribe_submit(wm_model* m, int slot, const float* mel, int mel_on_device, int B, const wm_decode_opts* opts);
 int wm_transcribe_wait(wm_model* m, int slot, int32_t* tokens_out, int32_t* n_tokens);
+/* wm_transcribe_wait for the multi-GPU path: the slot's result stays ON THE DEVICE, packed as the gather buffer the one
+ * collective of a batch moves — dev_packed [rows_cap, 1 + stride] int32 in the caller's DEVICE memory (e.g. a torch tensor handed to
+ * RCCL's all-gather): row r = [n_tokens[r], ids zero-padded to stride]; rows past the batch are zero (ragged shards gather a fixed
+ * row count per rank).  rows_cap >= B, stride >= n_prompt + 1 + max_loop.  Returns when the buffer is complete. */
+int wm_transcribe_wait_device(wm_model* m, int slot, int32_t* dev_packed, int rows_cap, int stride);
 /* Loop iterations that were enqueued for the slot's most recent completed pass (slot 0 also serves wm_transcribe): max_loop when
  * the pass ran to its bound, less when the early exit cut it.  -1: no pass yet / bad slot.  Diagnostics and tests. */
 int wm_transcribe_steps(wm_model* m, int slot);

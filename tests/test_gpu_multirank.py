@@ -100,3 +100,43 @@ def test_transcribe_sharded_two_ranks(hip, total):
     m.load(WeightLoader.from_array(synth.synth_weights(cfg, 0)))
     want = m.transcribe_batch(synth.synth_mels(cfg, 0, total), prompt=(1, 2, 3, 4), eot=-1, max_loop=12)
     assert res[0] == want and res[1] == want
+
+
+def test_device_gather_buffer_and_rccl_world_of_one(hip, tmp_path):
+    """The RCCL path as far as one GPU allows: `bench.py` with the ids left on the device as the gather buffer
+    (wm_transcribe_wait_device), a process group of ONE rank on backend "nccl" (RCCL initialises, all_gather_into_tensor runs on
+    the device buffer), against the host path of a plain run: same ids."""
+    dev, host = str(tmp_path / "dev.npy"), str(tmp_path / "host.npy")
+    r1 = _bench(1, 16, dev, {"WM_BENCH_DEVICE_GATHER": "1"})
+    r0 = _bench(1, 16, host, {})
+    assert r1["n_gpus"] == 1
+    a, b = np.load(host), np.load(dev)
+    assert a.shape == b.shape == (16, 4 + 1 + 99) and np.array_equal(a, b)
+
+
+def test_wait_device_packs_like_the_host(hip):
+    """wm_transcribe_wait_device: the [rows, 1 + stride] gather buffer built on the device equals dist.pack_tokens of the host
+    result — ragged row count, a stride wider than the pass, natural stop (utterances of different lengths), coalesced pairs."""
+    import torch
+    from whisper_mojo_amd import WhisperConfig, dist, synth
+    from whisper_mojo_amd.loader import WeightLoader
+    from whisper_mojo_amd.whisper import Whisper
+    cfg = WhisperConfig.micro()
+    w = synth.synth_weights(cfg, 0)
+    mels = synth.synth_mels(cfg, 0, 5)
+    for coalesce in (0, 2):
+        m = Whisper(cfg, max_batch=5, coalesce=coalesce)
+        m.load(WeightLoader.from_array(w))
+        free = m.transcribe_batch(mels, prompt=(1, 2, 3, 4), eot=-1, max_loop=20)
+        kw = dict(prompt=(1, 2, 3, 4), eot=free[0][4 + 5], max_loop=20)
+        want = m.transcribe_batch(mels, **kw)
+        assert len({len(x) for x in want}) > 1  # different lengths
+        toks, cnts = m.last_tokens.copy(), m.last_counts.copy()
+        for slot in (0, 1):
+            m.transcribe_submit(mels, slot=slot, **kw)
+        for slot in (0, 1):
+            packed = torch.full((7, 1 + 30), -1, dtype=torch.int32, device="cuda")
+            m.transcribe_wait_device(slot, packed)
+            assert np.array_equal(packed.cpu().numpy(), dist.pack_tokens(toks, cnts, 30, 7))
+            assert dist.gather_tokens_device(packed, 5) == want
+        m.close()

@@ -27,7 +27,7 @@ else
   # allocator), and recycling one after the HSA runtime has unloaded trips the CHECK (probe modes 3 / 4 say which pattern does).
   SIG='AddressSanitizer: CHECK failed: sanitizer_allocator_device.h:[0-9]* "((!dev_runtime_unloaded_)) != (0)"'
   probe_sig=0
-  for mode in 0 1 2 3 4; do
+  for mode in 0 1 2 3 4 5 6; do
     log=$(mktemp); rc=0
     "$PROBE" $mode > "$log" 2>&1 || rc=$?
     if grep -q "$SIG" "$log"; then probe_sig=1; echo "[probe mode $mode] exit $rc: shows the exit-time device-allocator CHECK (bare HIP program)";

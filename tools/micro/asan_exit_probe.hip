@@ -12,6 +12,14 @@
 //   mode 4: mode 0 + sixty 16 MB device buffers allocated and freed.  Unlike mode 3's 300 MB chunks (each larger than the whole
 //           quarantine budget, so recycled at once, while the runtime is alive) these STAY in the quarantine: at process exit it
 //           holds ~256 MB of freed DEVICE chunks, as after wm_model_free of a Whisper-tiny model (about 150 buffers of 1 KB-150 MB)
+//   mode 5: the library's HIP usage pattern without the library: two non-blocking streams, 150 device buffers of 1 KB-150 MB
+//           (1.3 GB), pinned host memory, an H2D copy from pageable memory on a stream, three instantiated graphs of 38 kernel
+//           nodes with 200-byte kernel arguments replayed 30 times, events — everything destroyed / freed before main returns
+//   mode 6: mode 0 + 1 200 device buffers of 1 MB allocated and freed LAST.  The quarantine budget is 256 MB and a recycle drains
+//           it to ~230 MB; with 1 MB chunks it then climbs back to within 1 MB of the budget, so the few MB the HIP / HSA teardown
+//           itself deletes at exit tip it over and the recycle that follows meets freed DEVICE chunks after the runtime has unloaded
+//           (coarse 16-300 MB chunks, modes 3-5, leave it up to a chunk below the budget: no recycle at exit).  wm_model_free ends
+//           with ~150 buffers of 1 KB-2.4 MB: the same fine-grained tail
 // Prints "Done." before returning, like examples/main.cpp.
 #include <hip/hip_runtime.h>
 
@@ -22,6 +30,15 @@
 __global__ void fill(float* p, int n, float v) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
+}
+struct BigArgs {
+    float* p;
+    int n;
+    char pad[200];
+};
+__global__ void fill_args(BigArgs a) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.n) a.p[i] += 1.0f;
 }
 __global__ void fill_lds(float* p, int n) {
     extern __shared__ float s[];
@@ -76,6 +93,54 @@ int main(int argc, char** argv) {
         std::vector<void*> bufs(60);
         for (auto& b : bufs) CK(hipMalloc(&b, (size_t)16 << 20));
         for (auto& b : bufs) CK(hipMemsetAsync(b, 0, (size_t)16 << 20, nullptr));
+        CK(hipDeviceSynchronize());
+        for (auto& b : bufs) CK(hipFree(b));
+    }
+    if (mode >= 5) {
+        hipStream_t st[2];
+        for (auto& q : st) CK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+        std::vector<void*> bufs;
+        const size_t sizes[] = {1 << 10, 16 << 10, 1 << 20, 2400 << 10, 9 << 20, 18 << 20, 75 << 20, 150 << 20};
+        size_t tot = 0;
+        for (int i = 0; tot < ((size_t)1300 << 20) && i < 150; ++i) {
+            void* b = nullptr;
+            const size_t sz = sizes[i % 8];
+            CK(hipMalloc(&b, sz));
+            CK(hipMemsetAsync(b, 0, sz, st[0]));
+            bufs.push_back(b);
+            tot += sz;
+        }
+        void* pinned = nullptr;
+        CK(hipHostMalloc(&pinned, 1 << 16, hipHostMallocMapped));
+        std::vector<float> pageable(240000, 1.f);
+        CK(hipMemcpyAsync(d, pageable.data(), pageable.size() * 4, hipMemcpyHostToDevice, st[1]));
+        hipEvent_t ev;
+        CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipGraphExec_t ge[3];
+        hipGraph_t g;
+        CK(hipStreamBeginCapture(st[1], hipStreamCaptureModeThreadLocal));
+        for (int k = 0; k < 38; ++k) {
+            BigArgs a{};
+            a.p = d;
+            a.n = 4096;
+            hipLaunchKernelGGL(fill_args, dim3(16), dim3(256), 0, st[1], a);
+        }
+        CK(hipStreamEndCapture(st[1], &g));
+        for (auto& e : ge) CK(hipGraphInstantiate(&e, g, nullptr, nullptr, 0));
+        CK(hipGraphDestroy(g));
+        for (int i = 0; i < 30; ++i) CK(hipGraphLaunch(ge[i % 3], st[1]));
+        CK(hipEventRecord(ev, st[1]));
+        CK(hipEventSynchronize(ev));
+        CK(hipStreamSynchronize(st[0]));
+        for (auto& e : ge) CK(hipGraphExecDestroy(e));
+        CK(hipEventDestroy(ev));
+        CK(hipHostFree(pinned));
+        for (void* b : bufs) CK(hipFree(b));
+        for (auto& q : st) CK(hipStreamDestroy(q));
+    }
+    if (mode >= 6) {
+        std::vector<void*> bufs(1200);
+        for (auto& b : bufs) CK(hipMalloc(&b, (size_t)1 << 20));
         CK(hipDeviceSynchronize());
         for (auto& b : bufs) CK(hipFree(b));
     }

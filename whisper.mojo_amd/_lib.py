@@ -17,7 +17,7 @@ if os.environ.get("WM_USE_DEV_LIB") and os.environ.get("WM_DEV_LIB_PATH"):  # a 
 SYMBOLS = [
     "wm_last_error", "wm_abi_version", "wm_model_load", "wm_model_load_memory", "wm_model_free", "wm_weight_count", "wm_weights_convert_v2", "wm_weights_read", "wm_state_new",
     "wm_state_reset", "wm_state_free", "wm_state_len", "wm_encode", "wm_state_set_encoder_output", "wm_decode_step",
-    "wm_transcribe", "wm_transcribe_submit", "wm_transcribe_wait", "wm_transcribe_steps", "wm_log_mel", "wm_transcribe_pcm", "wm_op_matmul_nt", "wm_op_ln_matmul_nt", "wm_op_mlp_block", "wm_op_attention", "wm_op_attention_cached", "wm_op_layer_norm", "wm_op_gelu", "wm_op_softmax_rows", "wm_op_conv1d_k3",
+    "wm_transcribe", "wm_transcribe_submit", "wm_transcribe_wait", "wm_transcribe_wait_device", "wm_transcribe_steps", "wm_log_mel", "wm_transcribe_pcm", "wm_op_matmul_nt", "wm_op_ln_matmul_nt", "wm_op_mlp_block", "wm_op_attention", "wm_op_attention_cached", "wm_op_layer_norm", "wm_op_gelu", "wm_op_softmax_rows", "wm_op_conv1d_k3",
     "wm_op_argmax", "wm_bench_kernel", "wm_bench_bytes", "wm_synth_weights", "wm_synth_mel_host",
 ]
 
@@ -79,6 +79,7 @@ def lib():
     L.wm_transcribe_submit.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(WmDecodeOpts)]
     L.wm_transcribe_wait.argtypes = [vp, C.c_int, ip, ip]
     L.wm_transcribe_steps.argtypes = [vp, C.c_int]
+    L.wm_transcribe_wait_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
     L.wm_log_mel.argtypes = [vp, fp, ip, C.c_int, C.c_int, fp]
     L.wm_transcribe_pcm.argtypes = [vp, fp, ip, C.c_int, C.c_int, C.POINTER(WmDecodeOpts), ip, ip]
     L.wm_op_matmul_nt.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int]

@@ -1390,6 +1390,18 @@ void launch_init_tokens(const InitTokensParams& p, hipStream_t st) {
     hipLaunchKernelGGL(init_tokens_kernel, dim3((p.B + 255) / 256), dim3(256), 0, st, p);
 }
 
+__global__ void pack_tokens_kernel(const int* __restrict__ out_tokens, const int* __restrict__ n_tokens, int out_stride, int rows, int stride,
+                                   int* __restrict__ dst) {
+    const int r = blockIdx.x;
+    int* d = dst + (size_t)r * (1 + stride);
+    const int n = r < rows ? min(n_tokens[r], stride) : 0;
+    if (threadIdx.x == 0) d[0] = n;
+    for (int j = threadIdx.x; j < stride; j += blockDim.x) d[1 + j] = j < n ? out_tokens[(size_t)r * out_stride + j] : 0;
+}
+void launch_pack_tokens(const int* out_tokens, const int* n_tokens, int out_stride, int rows, int rows_cap, int stride, int* dst, hipStream_t st) {
+    hipLaunchKernelGGL(pack_tokens_kernel, dim3(rows_cap), dim3(256), 0, st, out_tokens, n_tokens, out_stride, rows, stride, dst);
+}
+
 __global__ void set_step_kernel(StepCtl* ctl, int len, int set_len, int* pos, int pos_value, int* tok, int tok_value, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B) {

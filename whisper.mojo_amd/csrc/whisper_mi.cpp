@@ -795,8 +795,11 @@ static int state_new(wm_model* m, int B, wm_state** out, bool pair) {
     // latency models (B = 1: 12.1 -> 4 us per launch).  WM_NSPLIT overrides for tuning.
     {
         const int min_split = (int)((T + 511) / 512);
-        int ns = (1024 + m->cfg.max_batch - 1) / m->cfg.max_batch;
-        ns = std::max(12, std::min(48, ns));
+        // fp32 K/V rows are twice as wide: half the chunks move the same bytes per workgroup, the stream runs as fast (46.6 vs 46.5 us
+        // per launch at B = 64) and the merge reads half the partials (decode step 406 -> 402 us; 10 / 12 chunks: 418 / 412 us)
+        const int target = ks == 4 ? 512 : 1024;
+        int ns = (target + m->cfg.max_batch - 1) / m->cfg.max_batch;
+        ns = std::max(ks == 4 ? 8 : 12, std::min(48, ns));
         ns = std::max(min_split, std::min(ns, (int)((T + 31) / 32)));
         if (const char* e = wm_env("WM_NSPLIT")) ns = std::max(min_split, std::min(64, atoi(e)));
         s->nsplit = ns;
@@ -1756,7 +1759,8 @@ static int submit_on(wm_model* m, wm_state** slot, const float* mel, int mel_on_
 
 // Blocks until the state's pending pass is complete, then copies `rows` utterances starting at row0 out.  The pass stays pending
 // until every slot that shares the state (one, or the two of a coalesced pair) has collected its rows.
-static int wait_on(wm_model* m, wm_state* s, int32_t* tokens_out, int32_t* n_tokens, int row0 = 0, int rows = -1) {
+static int wait_on(wm_model* m, wm_state* s, int32_t* tokens_out, int32_t* n_tokens, int row0 = 0, int rows = -1, int32_t* dev_packed = nullptr,
+                   int rows_cap = 0, int pack_stride = 0) {
     if (!s || !s->pending) return fail(WM_E_STATE, "nothing was submitted on this slot");
     HIPCHK(hipSetDevice(m->device));
     if (rows < 0) rows = s->B;
@@ -1774,9 +1778,16 @@ static int wait_on(wm_model* m, wm_state* s, int32_t* tokens_out, int32_t* n_tok
         s->synced = true;
     }
     const int total = s->pend_total;
-    HIPCHK(hipMemcpy2D(tokens_out, (size_t)total * 4, s->out_tokens.as<int>() + (size_t)row0 * s->out_stride, (size_t)s->out_stride * 4, (size_t)total * 4, rows,
-                       hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(n_tokens, s->n_tokens.as<int>() + row0, (size_t)rows * 4, hipMemcpyDeviceToHost));
+    if (dev_packed) {  // the gather buffer, built on the device in the caller's DEVICE memory (no host round trip before the collective)
+        launch_pack_tokens(s->out_tokens.as<int>() + (size_t)row0 * s->out_stride, s->n_tokens.as<int>() + row0, s->out_stride, rows, rows_cap,
+                           pack_stride, dev_packed, s->lanes[0].st);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s->lanes[0].st));  // the caller's collective runs on another stream
+    } else {
+        HIPCHK(hipMemcpy2D(tokens_out, (size_t)total * 4, s->out_tokens.as<int>() + (size_t)row0 * s->out_stride, (size_t)s->out_stride * 4, (size_t)total * 4, rows,
+                           hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(n_tokens, s->n_tokens.as<int>() + row0, (size_t)rows * 4, hipMemcpyDeviceToHost));
+    }
     if (--s->halves_left <= 0) {
         s->pending = false;
         s->has_enc = false;  // the KV cache now holds a finished decode: a new wm_encode is needed before wm_decode_step
@@ -1895,6 +1906,25 @@ extern "C" int wm_transcribe_wait(wm_model* m, int slot, int32_t* tokens_out, in
     }
     wm_state* s = r.st;
     const int rc = wait_on(m, s, tokens_out, n_tokens, r.row0, r.rows);
+    if (!rc) m->last_steps[slot] = s->last_steps;
+    r = wm_model::SlotRef{};
+    return rc;
+}
+// wm_transcribe_wait with the result left ON THE DEVICE as the gather buffer of the multi-GPU path: dev_packed
+// [rows_cap, 1 + stride] int32 in the caller's device memory (e.g. a torch tensor), row r = [length, ids zero-padded]; rows past the
+// batch are zeroed.  stride >= n_prompt + 1 + max_loop of the pass.
+extern "C" int wm_transcribe_wait_device(wm_model* m, int slot, int32_t* dev_packed, int rows_cap, int stride) {
+    if (!m || !dev_packed || slot < 0 || slot >= wm_model::NSLOT || stride <= 0) return fail(WM_E_ARG, "bad argument");
+    wm_model::SlotRef& r = m->slot_ref[slot];
+    if (!r.pending) return fail(WM_E_STATE, "nothing was submitted on this slot");
+    if (rows_cap < r.rows) return fail(WM_E_ARG, "rows_cap %d is smaller than the batch (%d)", rows_cap, r.rows);
+    if (stride < r.total) return fail(WM_E_ARG, "stride %d is smaller than the pass's ids per utterance (%d)", stride, r.total);
+    if (m->held.active && m->held.slot == slot) {
+        const int rc = flush_held(m);
+        if (rc) return rc;
+    }
+    wm_state* s = r.st;
+    const int rc = wait_on(m, s, nullptr, nullptr, r.row0, r.rows, dev_packed, rows_cap, stride);
     if (!rc) m->last_steps[slot] = s->last_steps;
     r = wm_model::SlotRef{};
     return rc;

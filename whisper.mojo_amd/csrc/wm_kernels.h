@@ -258,6 +258,9 @@ struct InitTokensParams {
     TsRules rules;
 };
 void launch_init_tokens(const InitTokensParams& p, hipStream_t st);
+// rows of the gather buffer of SURVEY §8e: dst[r] = [n_tokens[r], ids of row r zero-padded to `stride`] for r < rows; rows in
+// [rows, rows_cap) are zeroed (ragged shards gather a fixed row count per rank)
+void launch_pack_tokens(const int* out_tokens, const int* n_tokens, int out_stride, int rows, int rows_cap, int stride, int* dst, hipStream_t st);
 void launch_set_step(StepCtl* ctl, int len, int set_len, int* pos, int pos_value, int* tok, int tok_value, int B,
                      hipStream_t st);
 

@@ -29,6 +29,7 @@ def pack_tokens(tokens: np.ndarray, counts: np.ndarray, stride: int, rows: int) 
     buf[:b, 0] = counts
     w = min(stride, tokens.shape[1])
     buf[:b, 1:1 + w] = tokens[:, :w]
+    buf[:b, 1:1 + w][np.arange(w)[None, :] >= np.asarray(counts)[:, None]] = 0  # what lies past an utterance's length is not its ids
     return buf
 
 
@@ -73,6 +74,27 @@ def gather_tokens(tokens: np.ndarray, counts: np.ndarray, total: int, stride: in
     for r in range(world):
         _, cnt = shard_range(total, r, world)
         res.extend(unpack_tokens(out[r * rows:r * rows + cnt]))
+    return res
+
+
+def gather_tokens_device(packed_local, total: int) -> List[List[int]]:
+    """The same collective on DEVICE buffers (backend "nccl" = RCCL over xGMI): `packed_local` is this rank's [rows, 1 + stride]
+    int32 CUDA tensor as Whisper.transcribe_wait_device leaves it (rows = ceil(total / world), zero rows past the shard) — no host
+    round trip before the all-gather; ONE device-to-host copy of the gathered [world * rows, 1 + stride] buffer after it."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        world, out = 1, packed_local
+    else:
+        world = dist.get_world_size()  # (a world of one still runs the collective: the one-GPU rehearsal of the RCCL path)
+        out = torch.empty((world * packed_local.shape[0], packed_local.shape[1]), dtype=torch.int32, device=packed_local.device)
+        dist.all_gather_into_tensor(out, packed_local)
+    rows = packed_local.shape[0]
+    host = out.cpu().numpy()
+    res: List[List[int]] = []
+    for r in range(world):
+        _, cnt = shard_range(total, r, world)
+        res.extend(unpack_tokens(host[r * rows:r * rows + cnt]))
     return res
 
 

@@ -239,6 +239,16 @@ class Whisper:
         self.last_tokens, self.last_counts = toks, n
         return [toks[b, :n[b]].tolist() for b in range(B)]
 
+    def transcribe_wait_device(self, slot: int, packed) -> None:
+        """transcribe_wait with the ids left on the GPU as the multi-GPU gather buffer: `packed` is a torch int32 CUDA tensor
+        [rows, 1 + stride] on this model's device; row r becomes [length, ids zero-padded] (dist.gather_tokens_device)."""
+        B, total, _keep = self._pending.pop(slot)
+        rows, width = int(packed.shape[0]), int(packed.shape[1])
+        if not packed.is_cuda or packed.dtype.itemsize != 4 or not packed.is_contiguous():
+            raise ValueError("packed must be a contiguous int32 CUDA tensor")
+        _lib.check(_lib.lib().wm_transcribe_wait_device(self._h, slot, C.c_void_p(packed.data_ptr()), rows, width - 1))
+        self.last_tokens = self.last_counts = None
+
     def loop_steps(self, slot: int = 0) -> int:
         """Loop iterations (whisper.mojo:205) enqueued for the slot's most recent completed pass: max_loop unless the early exit
         (every utterance emitted eot, whisper.mojo:206-207) cut the loop.  Slot 0 also serves transcribe_batch."""
