@@ -130,7 +130,7 @@ def test_wait_device_packs_like_the_host(hip):
         free = m.transcribe_batch(mels, prompt=(1, 2, 3, 4), eot=-1, max_loop=20)
         kw = dict(prompt=(1, 2, 3, 4), eot=free[0][4 + 5], max_loop=20)
         want = m.transcribe_batch(mels, **kw)
-        assert len({len(x) for x in want}) > 1  # different lengths
+        assert min(len(x) for x in want) < 25  # an early stop: the device rows hold stale ids of the longer pass behind their length
         toks, cnts = m.last_tokens.copy(), m.last_counts.copy()
         for slot in (0, 1):
             m.transcribe_submit(mels, slot=slot, **kw)

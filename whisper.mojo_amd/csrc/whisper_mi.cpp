@@ -1170,7 +1170,10 @@ static int launch_cross_attn(wm_model* m, wm_state* s, int l, const DecView& v, 
     a.nq = (P == 4 && !no_mq) ? 4 : 0;  // the reference's 4-token prompt: one K/V sweep for the four positions
     a.ts = (long long*)m->ts_buf.p;
     a.ts_id = s->trace_id;
-    a.lds_pad = s->shares_chip ? 34 * 1024 : 0;
+    // fewer K/V-streaming workgroups per CU when passes share the chip (AttnDecParams.lds_pad).  16-bit K/V: 34 KB of pad (+ 20 KB
+    // static) = two per CU.  fp32 K/V (12 KB static): ONE per CU measured best with four 128-row passes in flight — pipelined ms per
+    // 64-clip pass: pad 0 (four per CU) 28.2, 20 KB 28.4, 34 KB (three) 27.8, 42 / 50 / 60 KB (two) 27.3 / 27.5 / 27.4, 90 KB (one) 27.05
+    a.lds_pad = s->shares_chip ? (m->cfg.kv_dtype == WM_F32 ? 90000 : 34 * 1024) : 0;
     return attn_decode_dispatch(m->cfg.kv_dtype, a, v.st);
 }
 
