@@ -413,7 +413,6 @@ def main():
                              "note": "random-init weights almost never emit eot: natural mode runs to the 195-iteration bound"}
         # the same stop rule with an eot every utterance reaches: 64 copies of clip 0, eot := the id it emits at iteration 60 — the
         # loop is cut there (whisper.mojo:206-207), at most two sub-chunks of 8 steps late
-        import torch
         same = b.mel_dev[:1].expand(b.count, -1, -1).contiguous()
         free = b.model.transcribe_batch(same[:1], max_loop=NATURAL_LOOP, ignore_eot=True)[0]
         eot = int(free[4 + 60])
@@ -426,7 +425,7 @@ def main():
         extras["natural_reachable_eot"] = {"what": "64 copies of clip 0, eot := the id it emits at loop iteration 60", "eot_at_iteration": stop,
                                            "loop_iterations_enqueued": steps_run, "steps": nat_n, "ms_per_step": round(r_dt / nat_n * 1e3, 3),
                                            "synchronous_ms_per_step": round(rs_dt / 2 * 1e3, 3), "synchronous_loop_iterations": b.model.loop_steps(0)}
-        del same, torch
+        del same
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         rtf, tok_s = b.rates(dt, args.steps, DECODE_STEPS + 1)
