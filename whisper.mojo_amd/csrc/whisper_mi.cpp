@@ -941,7 +941,13 @@ static int cross_kv_chunk(wm_model* m, wm_state* s, int c0, int bc, hipStream_t 
 }
 
 // mel2 / split_at (coalesced pairs): utterances [split_at, B) come from mel2 (their own batch's buffer); split_at is a multiple of Bc
-static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hipStream_t st, const float* mel2 = nullptr, int split_at = 0) {
+// want_f32: also produce the fp32 encoder output (s->enc_f, what wm_encode returns).  The decoder never reads it — the cross-K/V
+// projection consumes the operand-dtype rows s->enc_t — so the transcribe paths skip it, and where the last fc2 can carry a
+// LayerNorm in its epilogue (16-bit operands, d = 384) `ln_post` rides there: no LayerNorm launch, no 147 MB fp32 write per pass.
+// BOTH kinds of caller take the operand rows from the same epilogue, so wm_encode + wm_decode_step and wm_transcribe see
+// bit-identical cross-K/V (round 2 had fused it for the transcribe paths only and reverted: the two entry points parted at a near-tie).
+static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hipStream_t st, const float* mel2 = nullptr, int split_at = 0,
+                       bool want_f32 = true) {
     const wm_dims& c = m->cfg.dims;
     const int T = m->cfg.compute_dtype;
     const size_t d = c.d_model, L = 2 * (size_t)c.n_audio_ctx, NT = c.n_audio_ctx, ts = dt_size(T);
@@ -951,6 +957,7 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
         const int M = (int)(bc * NT);
         const int opb = T == WM_F32 ? 4 : 2;
         bool xn_is_ln1 = false;  // xn holds LN1(x) of the coming block, written by the epilogue of the GEMM that produced x
+        bool post_fused = false;  // enc_t was written by the last fc2's epilogue
         const float* mel_c = (mel2 && c0 >= split_at) ? mel2 + (size_t)(c0 - split_at) * c.n_mels * L : mel_dev + (size_t)c0 * c.n_mels * L;
         DISPATCH_DT(T, TT, launch_mel_transpose_pad<TT>(mel_c, s->mel_t.p, bc, c.n_mels, (int)L, m->Cp, st));
         {  // conv1 + GELU -> h1 rows 1..L (token-major)   whisper.mojo:73-75
@@ -1064,16 +1071,25 @@ static int run_encoder(wm_model* m, wm_state* s, const float* mel_dev, int B, hi
             f2.bias = w.fc2_b.as<float>();
             f2.residual = s->x.as<float>();
             f2.ldr = d;
-            xn_is_ln1 = l + 1 < c.n_layers && gemm_nt_fuses_layernorm_out(opb, f2);
+            const bool fuse_out = gemm_nt_fuses_layernorm_out(opb, f2);
+            xn_is_ln1 = l + 1 < c.n_layers && fuse_out;
             if (xn_is_ln1) {  // the next block's LN1
                 f2.lno_g = m->enc[l + 1].ln1_g.as<float>();
                 f2.lno_b = m->enc[l + 1].ln1_b.as<float>();
                 f2.lno_out = s->xn.p;
+            } else if (fuse_out) {  // last block: ln_post (whisper.mojo:97-98) as operand rows for the cross-K/V projection
+                f2.lno_g = m->enc_ln_g.as<float>();
+                f2.lno_b = m->enc_ln_b.as<float>();
+                f2.lno_out = s->enc_t.p;
+                post_fused = true;
             }
             WMCHK(gemm_dispatch(T, WM_F32, f2, 1, st));
         }
         float* encf = s->enc_f.as<float>() + (size_t)c0 * NT * d;
-        DISPATCH_DT(T, TT, launch_layernorm_rows<TT>(s->x.as<float>(), m->enc_ln_g.as<float>(), m->enc_ln_b.as<float>(), s->enc_t.p, encf, M, c.d_model, 1e-5f, st));
+        if (!post_fused)  // operand rows (and the fp32 copy) from the LayerNorm kernel
+            DISPATCH_DT(T, TT, launch_layernorm_rows<TT>(s->x.as<float>(), m->enc_ln_g.as<float>(), m->enc_ln_b.as<float>(), s->enc_t.p, want_f32 ? encf : nullptr, M, c.d_model, 1e-5f, st));
+        else if (want_f32)  // the fp32 copy only
+            DISPATCH_DT(T, TT, launch_layernorm_rows<TT>(s->x.as<float>(), m->enc_ln_g.as<float>(), m->enc_ln_b.as<float>(), nullptr, encf, M, c.d_model, 1e-5f, st));
         WMCHK(cross_kv_chunk(m, s, c0, bc, st));
     }
     HIPCHK(hipGetLastError());
@@ -1100,7 +1116,7 @@ extern "C" int wm_encode(wm_model* m, wm_state* s, const float* mel, int mel_on_
         HIPCHK(hipMemcpyAsync(s->mel_dev.p, mel, (size_t)B * c.n_mels * 2 * c.n_audio_ctx * 4, hipMemcpyHostToDevice, m->stream));
         mel_dev = s->mel_dev.as<float>();
     }
-    WMCHK(run_encoder(m, s, mel_dev, B, m->stream));
+    WMCHK(run_encoder(m, s, mel_dev, B, m->stream, nullptr, 0, enc_out != nullptr));
     s->has_enc = s->has_cross = true;
     s->last_mel = mel_dev;
     if (enc_out) HIPCHK(hipMemcpyAsync(enc_out, s->enc_f.p, (size_t)B * c.n_audio_ctx * c.d_model * 4, hipMemcpyDeviceToHost, m->stream));
@@ -1740,7 +1756,7 @@ static int submit_on(wm_model* m, wm_state** slot, const float* mel, int mel_on_
     }
     const auto tt0 = std::chrono::steady_clock::now();
     trace_mark(est, "state %p encoder start", (void*)s);
-    WMCHK(run_encoder(m, s, mel_dev, B, est, mel2_dev, B1));
+    WMCHK(run_encoder(m, s, mel_dev, B, est, mel2_dev, B1, false));
     trace_mark(est, "state %p encoder end", (void*)s);
     s->enc_stream = est;
     s->has_enc = s->has_cross = true;
@@ -2254,9 +2270,9 @@ extern "C" int wm_bench_kernel(wm_model* m, wm_state* s, int which, int reps, fl
 #endif
     } else if (which == WM_KERNEL_ENCODER) {
         if (!s->last_mel) return fail(WM_E_STATE, "no mel was encoded into this state");
-        WMCHK(run_encoder(m, s, s->last_mel, s->B, st));
+        WMCHK(run_encoder(m, s, s->last_mel, s->B, st, nullptr, 0, false));  // as the transcribe paths run it
         HIPCHK(hipEventRecord(e0, st));
-        for (int i = 0; i < reps; ++i) WMCHK(run_encoder(m, s, s->last_mel, s->B, st));
+        for (int i = 0; i < reps; ++i) WMCHK(run_encoder(m, s, s->last_mel, s->B, st, nullptr, 0, false));
         HIPCHK(hipEventRecord(e1, st));
     } else {
         return fail(WM_E_ARG, "unknown kernel id %d", which);
