@@ -77,6 +77,20 @@ def test_gpu_timestamp_rules_in_fused_argmax(micro_cfg, micro_weights):
     for i in range(len(seeds)):
         want = M.transcribe(mel=mels[i], timestamps=_ts(g), prompt=g["prompt"], eot=int(g["eos"]), max_loop=g["plain"].shape[1] - 5)
         assert stop[i] == want.tolist()
+    # round 3: the rules, the suppress lists and the stop rule through COALESCED submits (two batches on one 2·B-row state, the
+    # per-utterance rule state TsState for 2·B rows, the loop fed by the pump thread) — each batch still gets exactly its own ids
+    c = Whisper(micro_cfg, max_batch=len(seeds), coalesce=2)
+    c.load(WeightLoader.from_array(micro_weights))
+    rev = mels[::-1].copy()
+    kws = dict(timestamps=_ts(g), prompt=g["prompt"], eot=int(g["eos"]), max_loop=g["plain"].shape[1] - 5)
+    c.transcribe_submit(mels, slot=0, **kws)
+    c.transcribe_submit(rev, slot=1, **kws)
+    assert c.transcribe_wait(0) == stop and c.transcribe_wait(1) == stop[::-1]
+    kwa = dict(kw, timestamps=_ts(g), suppress_tokens=g["suppress"][0], begin_suppress_tokens=g["begin_suppress"][0])
+    c.transcribe_submit(mels[:2], slot=2, **kwa)
+    c.transcribe_submit(mels[:2], slot=3, **kwa)
+    assert c.transcribe_wait(3) == both and c.transcribe_wait(2) == both
+    c.close()
 
 
 @pytest.mark.gpu
