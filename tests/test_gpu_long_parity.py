@@ -16,9 +16,9 @@ pytestmark = pytest.mark.gpu
 
 F32_TOL = 5e-5      # fp32 mode: |logit - oracle| (values O(1); different summation order)
 MARGIN_TOL = 1e-3   # fp32 mode: a token may differ from the oracle's only where the oracle's own margin is below this
-BF16_TOL = 0.06     # bf16 operands + bf16 KV over 100 positions (measured: 0.031 max over the 8 sampled utterances x 100 positions)
+BF16_TOL = 0.06     # bf16 operands + bf16 KV over 100 positions (measured: 0.031 max over 8 utterances x 100 positions in round 2)
 F16_TOL = 0.012     # f16 operands + f16 KV, base dims (measured: 0.0057 over 2 utterances x 40 positions)
-ENC16_TOL = 0.03    # bf16 ENCODER GEMMs only, decoder + KV fp32 (BASELINE config 3 as written): measured 0.013 at B = 1 over 25 positions
+ENC16_TOL = 0.03    # bf16 ENCODER GEMMs only, decoder + KV fp32 (BASELINE config 3 as written): measured 0.0162 over 64 utterances x 100 positions
 PROMPT = (50258, 50259, 50359, 50363)
 
 
@@ -222,6 +222,9 @@ def test_micro_longest_stream_ids(hip, oracle_mod, micro_cfg, micro_weights):
 
 
 # ------------------------------------------------------------------------------------------------ (b) config 3 as benched
+_ORACLE_RUNS = {}  # (d_model, n_layers, utterance, steps) -> (ids, logits) of the fp32 oracle on seed-0 weights, mel seed 1000 + utterance
+
+
 def _sixteen_bit_case(oracle_mod, cfg, weights, dtype, tol, sampled, positions, min_clear, decoder_fp32=False, alone=None):
     """B = 64 in a 16-bit mode against the oracle for the `sampled` utterances (seeds 1000 + u, as bench.py).  decoder_fp32: the
     16-bit dtype applies to the encoder GEMMs only; decoder weights / operands / KV cache fp32 (BASELINE config 3 as written)."""
@@ -231,8 +234,11 @@ def _sixteen_bit_case(oracle_mod, cfg, weights, dtype, tol, sampled, positions, 
     ref = oracle_mod.OracleModel(cfg, weights)
     steps = positions - 1  # 1 id from the prefill + `steps` loop iterations
     want, wlog = {}, {}
-    for u in sampled:
-        want[u], wlog[u] = ref.transcribe(mel=mels[u], max_loop=steps, ignore_eot=True, want_logits=True)
+    for u in sampled:  # the oracle's streams / logits depend on (model dims, utterance, length) only: shared between the B = 64 tests
+        key = (cfg.d_model, cfg.n_layers, u, steps)
+        if key not in _ORACLE_RUNS:
+            _ORACLE_RUNS[key] = ref.transcribe(mel=mels[u], max_loop=steps, ignore_eot=True, want_logits=True)
+        want[u], wlog[u] = _ORACLE_RUNS[key]
     m = make_model(cfg, weights, compute_dtype=dtype, kv_dtype=0 if decoder_fp32 else dtype, max_batch=B, decoder_fp32=decoder_fp32)
     # teacher-forced on the oracle's streams: utterance u decodes the stream of sampled[u % len]; only the sampled rows are compared
     streams = np.stack([want[sampled[u % len(sampled)]] if u not in want else want[u] for u in range(B)]).astype(np.int32)[:, :-1]
@@ -267,17 +273,18 @@ def _sixteen_bit_case(oracle_mod, cfg, weights, dtype, tol, sampled, positions, 
 
 
 def test_config3_tiny_b64_bf16_against_oracle(hip, oracle_mod, tiny_cfg, tiny_weights):
-    """BASELINE config 3 exactly as bench.py runs it: 64 clips, bf16 operands + bf16 KV cache, 1 prefill + 99 steps."""
-    worst, n_clear = _sixteen_bit_case(oracle_mod, tiny_cfg, tiny_weights, 1, BF16_TOL, [0, 7, 15, 16, 31, 40, 55, 63], 100, 600)
-    print(f"config 3: max |logit error| {worst:.4f} over 8 x 100 positions, {n_clear} positions with a clear margin")
+    """The all-16-bit variant of config 3 (`value_all_16bit`, round 2's headline): 64 clips, bf16 operands + bf16 KV cache,
+    1 prefill + 99 steps — all 64 utterances against the oracle (round 2 sampled 8)."""
+    worst, n_clear = _sixteen_bit_case(oracle_mod, tiny_cfg, tiny_weights, 1, BF16_TOL, list(range(64)), 100, 5600, alone=(0, 31, 63))  # measured 0.0327, 6 019 clear
+    print(f"all-16-bit tiny B=64: max |logit error| {worst:.4f} over 64 x 100 positions, {n_clear} positions with a clear margin")
 
 
 def test_config3_literal_bf16_encoder_fp32_decoder_all_64_clips(hip, oracle_mod, tiny_cfg, tiny_weights):
     """BASELINE config 3 AS WRITTEN and as `python bench.py` runs it by default (workload tiny_b64_bf16enc_f32dec): 64 clips,
     bf16 encoder GEMMs on MFMA, decoder weights / operands / KV cache fp32, 1 prefill + 99 steps.  ALL 64 utterances against the
     oracle, 100 positions each, teacher-forced on the oracle's own greedy streams."""
-    worst, n_clear = _sixteen_bit_case(oracle_mod, tiny_cfg, tiny_weights, 1, ENC16_TOL, list(range(64)), 100, 5200,
-                                       decoder_fp32=True, alone=(0, 31, 63))
+    worst, n_clear = _sixteen_bit_case(oracle_mod, tiny_cfg, tiny_weights, 1, ENC16_TOL, list(range(64)), 100, 5900,
+                                       decoder_fp32=True, alone=(0, 31, 63))  # measured 0.0162, 6 259 clear
     print(f"config 3 as written: max |logit error| {worst:.4f} over 64 x 100 positions, {n_clear} positions with a clear margin")
 
 
@@ -286,7 +293,7 @@ def test_config5_base_b64_f16_against_oracle(hip, oracle_mod):
     from whisper_mojo_amd import WhisperConfig
     cfg = WhisperConfig.base()
     w = oracle_mod.synth_weights_c(cfg, 0)
-    worst, n_clear = _sixteen_bit_case(oracle_mod, cfg, w, 2, F16_TOL, [0, 3, 9, 17, 31, 42, 60, 63], 100, 700)
+    worst, n_clear = _sixteen_bit_case(oracle_mod, cfg, w, 2, F16_TOL, [0, 3, 9, 17, 31, 42, 60, 63], 100, 740)  # measured 0.0062, 790 clear
     print(f"config 5: max |logit error| {worst:.4f} over 8 x 100 positions, {n_clear} positions with a clear margin")
 
 
