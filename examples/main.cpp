@@ -3,10 +3,13 @@
 //
 //   whisper_main [--config tiny|base|micro] [--weights FILE | --synthetic-weights SEED] [--mel FILE | --synthetic-mel SEED]
 //                [--vocab vocab.txt] [--dtype f32|bf16|f16] [--max-loop N] [--ignore-eot] [--prompt a,b,c,d] [--eot ID]
+//                [--pipelined N]  after the reference's flow: the same clip N times through transcribe_submit / transcribe_wait
+//                                 (coalesced in pairs by the library), every result checked against the synchronous call's
 //
 // Defaults are the reference's file names (whisper_tiny_weights.bin, sample_input.bin, vocab.txt).  The synthetic options
 // use the library's own generator (wm_synth_weights / wm_synth_mel_host) so the program runs without the reference's
 // (network-hosted) weights; tests compare its ids with the Python host layer on the same seeds.
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <iostream>
@@ -21,6 +24,7 @@ int main(int argc, char** argv) {
     long synth_w = -1, synth_m = -1;
     int max_loop = Whisper::MAX_LOOP;
     bool ignore_eot = false;
+    int pipelined = 0;
     std::vector<int32_t> prompt;
     int eot = Whisper::EOT;
     for (int i = 1; i < argc; ++i) {
@@ -41,6 +45,7 @@ int main(int argc, char** argv) {
         else if (a == "--dtype") dtype = next();
         else if (a == "--max-loop") max_loop = std::atoi(next().c_str());
         else if (a == "--ignore-eot") ignore_eot = true;
+        else if (a == "--pipelined") pipelined = std::atoi(next().c_str());
         else if (a == "--eot") eot = std::atoi(next().c_str());
         else if (a == "--prompt") {
             std::stringstream ss(next());
@@ -55,7 +60,7 @@ int main(int argc, char** argv) {
         const WhisperConfig cfg = config == "base" ? WhisperConfig::base() : config == "micro" ? WhisperConfig::micro() : WhisperConfig::tiny();
         const int dt = dtype == "bf16" ? WM_BF16 : dtype == "f16" ? WM_F16 : WM_F32;
         std::cout << "Initializing Whisper (" << config << ") on MI355X...\n";
-        Whisper whisper(cfg, dt);
+        Whisper whisper(cfg, dt, -1, 1, 0, pipelined > 0 ? 2 : 0);
         if (!prompt.empty() || eot != Whisper::EOT) whisper.set_prompt(prompt.empty() ? std::vector<int32_t>(Whisper::PROMPT, Whisper::PROMPT + 4) : prompt, eot);
         if (synth_w >= 0) {
             std::cout << "Generating synthetic weights (seed " << synth_w << ")...\n";
@@ -91,6 +96,17 @@ int main(int argc, char** argv) {
                       << tokenizer.decode(tokens) << "\n========================================\n";
         } else {
             std::cout << "\n(no " << vocab << ": ids only)\n";
+        }
+        if (pipelined > 0) {  // back-to-back calls: submit up to eight, collect them, compare with the list above
+            int bad = 0;
+            for (int k0 = 0; k0 < pipelined; k0 += 8) {
+                const int n = std::min(8, pipelined - k0);
+                for (int sl = 0; sl < n; ++sl) whisper.transcribe_submit(mel.ptr(), 1, sl, max_loop, ignore_eot);
+                for (int sl = 0; sl < n; ++sl)
+                    if (whisper.transcribe_wait(sl)[0] != tokens) ++bad;
+            }
+            std::cout << "\nPipelined: " << pipelined << " submits, " << bad << " differ from the synchronous result\n";
+            if (bad) return 1;
         }
         std::cout << "\nDone." << std::endl;  // flushed here: everything main printed is out before any exit-time teardown
     } catch (const std::exception& e) {

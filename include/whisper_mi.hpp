@@ -82,13 +82,14 @@ public:
     static constexpr int MAX_LOOP = 195;                                 // whisper.mojo:205
 
     explicit Whisper(const WhisperConfig& cfg = WhisperConfig::tiny(), int compute_dtype = WM_F32, int kv_dtype = -1,
-                     int max_batch = 1, int device = 0)
+                     int max_batch = 1, int device = 0, int coalesce = 0)
         : cfg_(cfg), device_(device) {
         wcfg_.dims = cfg.dims();
         wcfg_.gelu_mode = WM_GELU_TANH;  // whisper_tensor.mojo:288-308
         wcfg_.compute_dtype = compute_dtype;
         wcfg_.kv_dtype = kv_dtype < 0 ? compute_dtype : kv_dtype;
         wcfg_.max_batch = max_batch;
+        wcfg_.coalesce = coalesce;  // 2: consecutive transcribe_submit calls share one 2·B-row decode state (wm_config.coalesce)
     }
     Whisper(const Whisper&) = delete;
     Whisper& operator=(const Whisper&) = delete;

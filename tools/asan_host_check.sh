@@ -60,6 +60,10 @@ else
   for dt in f32 bf16; do
     run --config micro --synthetic-weights 0 --synthetic-mel 1000 --dtype $dt --prompt 1,2,3,4 --eot 532 --max-loop 40 --vocab /nonexistent
   done
+  # the pipelined entry under the sanitizer: coalesced pairs (a held submit, pair states, row demultiplexing) and the library's
+  # pump thread feeding natural-stop loops in sub-chunks (max-loop 40 > two sub-chunks) — 13 submits: six pairs and a leftover
+  run --config micro --synthetic-weights 0 --synthetic-mel 1000 --dtype f32 --prompt 1,2,3,4 --eot 999999 --max-loop 40 --vocab /nonexistent --pipelined 13
+  run --config micro --synthetic-weights 0 --synthetic-mel 1000 --dtype bf16 --prompt 1,2,3,4 --eot 532 --max-loop 40 --vocab /nonexistent --pipelined 5
   # Whisper-tiny in bf16: the encoder's row-panel / full-row GEMM launchers and the fused LayerNorm plumbing (d = 384 only)
   run --config tiny --synthetic-weights 0 --synthetic-mel 1000 --dtype bf16 --max-loop 6 --vocab /nonexistent
   echo "ASAN/UBSAN host check: clean"
