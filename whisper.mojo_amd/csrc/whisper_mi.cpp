@@ -1728,7 +1728,7 @@ static int submit_on(wm_model* m, wm_state** slot, const float* mel, int mel_on_
         WMCHK(state_new(m, B, slot, pair));
     }
     wm_state* s = *slot;
-    s->trace_id = slot == &m->cached ? 1 : (slot >= m->slots && slot < m->slots + wm_model::NSLOT - 1) ? 2 + (int)(slot - m->slots) : 10 + (int)(slot - m->pairs);
+    s->trace_id = slot == &m->cached ? 1 : (slot >= m->slots && slot < m->slots + (wm_model::NSLOT - 1)) ? 2 + (int)(slot - m->slots) : 10 + (int)(slot - m->pairs);
     // The whole pass — encoder, prefill, greedy loop — goes on the slot's own stream: four slots are then four hardware
     // queues, which is what the chip runs concurrently (a fifth queue, e.g. a shared encoder stream, lands on a pipe that
     // already serves one of them and the two take turns: 22.3 vs 20.8 ms per pass at four passes in flight).
