@@ -273,6 +273,12 @@ static int dec_linear_waves(int K, int elem_bytes = 2) {
     if (K <= 0 || (K & 31)) return 0;
     const int ksteps = K >> 5;
     if (elem_bytes == 4) {  // fp32 operands (eight exact-fp32 MFMAs per k-step): one k-step per wave stays fastest (B = 1: 211 vs 223 us per step)
+        static const int kpw32 = wm_env("WM_LIN_KPW32") ? atoi(wm_env("WM_LIN_KPW32")) : 0;  // dev A/B: k-steps per wave for fp32 operands
+        if (kpw32 > 0) {
+            for (int lim = kpw32; lim <= 4; ++lim)
+                for (int c = 1; c <= 16; ++c)
+                    if (ksteps % c == 0 && ksteps / c <= lim) return c;
+        }
         for (int c = 16; c >= 1; --c)
             if (ksteps % c == 0 && ksteps / c <= 4) return c;
         return 0;
