@@ -250,7 +250,6 @@ struct wm_state {
     std::vector<Lane> lanes;
     hipEvent_t enc_done = nullptr;
     hipStream_t enc_stream = nullptr;  // stream the pending pass's encoder was enqueued on
-    StepCtl* h_ctl = nullptr;  // pinned host copy of the control blocks (finish polling)
     int graph_eot = 0, graph_ignore = 0;
     bool graphs_valid = false;
     bool pending = false;   // a submitted pass has not been waited for yet
@@ -758,7 +757,6 @@ extern "C" void wm_state_free(wm_state* s) {
     if (s->enc_done) (void)hipEventDestroy(s->enc_done);
     for (auto& ev : s->chunk_ev)
         if (ev) (void)hipEventDestroy(ev);
-    if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     if (s->h_prog) (void)hipHostFree((void*)s->h_prog);
     DevBuf* bs[] = {&s->mel_dev, &s->mel_t, &s->h1, &s->x, &s->xn, &s->qkv, &s->ao, &s->hid, &s->enc_t, &s->enc_f,
                     &s->cross_kv, &s->self_kv, &s->dx, &s->dq, &s->dattn, &s->dhid, &s->part_o, &s->part_ml, &s->logits, &s->amax_val, &s->amax_idx, &s->ts_state, &s->ts_val, &s->ts_idx, &s->ts_m, &s->ts_s, &s->mask_steady, &s->mask_begin,
@@ -890,7 +888,6 @@ static int state_new(wm_model* m, int B, wm_state** out, bool pair) {
             s->lanes.pop_back();
         }
         hipError_t e = hipEventCreateWithFlags(&s->enc_done, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_ctl, sizeof(StepCtl) * 8, 0);
         if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_prog, 64, hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&s->d_prog, (void*)s->h_prog, 0);
         for (auto& ev : s->chunk_ev)
@@ -1550,11 +1547,11 @@ static void pump_main(wm_model* m) {
 }
 
 // ---- Whisper.transcribe: whisper.mojo:184-223 ------------------------------------------------------------------------
-// Enqueues the whole greedy loop for state s on its decode lane streams; returns without waiting.  The lanes first wait
-// for the encoder (recorded on the model stream).  allow_poll: the synchronous entry point may stop early when every
-// utterance has emitted eot; the pipelined one enqueues all max_loop steps (finished utterances stop recording).
+// Enqueues the prompt prefill and the greedy loop for state s on its decode lane streams; returns without waiting.  The lanes
+// first wait for the encoder (recorded on the stream it ran on).  Both entry points stop once every utterance has emitted eot
+// (whisper.mojo:206-207): allow_poll = the synchronous one feeds its loop itself, sub-chunk by sub-chunk; the pipelined one
+// hands the rest of the loop to the model's pump thread (see the enqueue machinery above).
 static int transcribe_decode(wm_model* m, wm_state* s, const wm_decode_opts* o, bool allow_poll) {
-    const int B = s->B;
     HIPCHK(hipEventRecord(s->enc_done, s->enc_stream ? s->enc_stream : m->stream));  // encoder + cross K/V of this state
     static const bool trace_phase = wm_env("WM_TRACE_HOST") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
