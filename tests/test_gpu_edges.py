@@ -249,3 +249,23 @@ def test_coalesced_tiny_b64_pairs_equal_uncoalesced(hip, tiny_cfg, tiny_weights)
     assert m.transcribe_wait(0) == want[0] and m.transcribe_wait(1) == want[1]
     assert m.transcribe_wait(2) == want[1] and m.transcribe_wait(3) == want[0]
     m.close()
+
+
+def test_logits_128_row_kernel_equals_64_row_kernel(hip, micro_cfg, micro_weights):
+    """Decode states of more than 64 rows take the 128-rows-per-workgroup logits kernel (fp32 decoder: two K passes over three
+    bf16 images; LayerNorm statistics summed in the 64-row kernel's order).  Its ids must equal the 64-row kernel's bit for
+    bit: B = 80 in one state against the same utterances in batches of 40 (64-row kernel), and 40 + 40 coalesced."""
+    from whisper_mojo_amd import synth
+    mels = synth.synth_mels(micro_cfg, 300, 80)
+    kw = dict(prompt=(1, 2, 3, 4), eot=-1, max_loop=24)
+    small = make_model(micro_cfg, micro_weights, max_batch=40)
+    want = small.transcribe_batch(mels[:40], **kw) + small.transcribe_batch(mels[40:], **kw)
+    small.close()
+    big = make_model(micro_cfg, micro_weights, max_batch=80)
+    assert big.transcribe_batch(mels, **kw) == want
+    big.close()
+    pair = make_model(micro_cfg, micro_weights, max_batch=40, coalesce=2)
+    pair.transcribe_submit(mels[:40], slot=0, **kw)
+    pair.transcribe_submit(mels[40:], slot=1, **kw)
+    assert pair.transcribe_wait(0) + pair.transcribe_wait(1) == want
+    pair.close()

@@ -868,6 +868,206 @@ __global__ __launch_bounds__(512) void dec_logits_split_kernel(DecLinearParams p
     WM_LG_STAMP(4);
 }
 #undef WM_LG_STAMP
+// The same kernel for 128 rows per workgroup — two coalesced 64-utterance batches on one decode state (wm_config.coalesce): with 64
+// rows per workgroup a 128-row state streamed the 80 MB embedding twice per step.  Three bf16 images of 128 x 384 do not fit the
+// 160 KB of LDS, so K goes in TWO passes of K/2 columns: stage the first half of every row, multiply it with k-steps 0 .. K/64-1 of
+// the workgroup's embedding rows (the second half's weight fragments are requested meanwhile, register set by register set), barrier,
+// re-stage, multiply the second half into the same accumulators.  Every row's arithmetic is exactly the 64-row kernel's — the
+// LayerNorm statistics are summed in the same order (a thread carries the two partial sums of the two "virtual" threads the
+// 8-threads-per-row scheme gives its elements to), the k-steps accumulate in the same order — so the ids of a coalesced pass equal
+// the uncoalesced ones bit for bit.
+template <int KD /* d_model/128 */>
+__global__ __launch_bounds__(512) void dec_logits_split128_kernel(DecLinearParams p, int CT) {
+    constexpr int NRB = 8, ROWS = 128;
+    constexpr int K = KD * 128, KH = K / 2;  // columns per pass
+    constexpr int PITCH = KH + 16;           // ≡ 8 dwords (mod 16): conflict-free fragment reads (see dec_logits_split_kernel)
+    constexpr int KSH = KD * 2;              // k-steps of 32 per pass
+    constexpr int IMG = ROWS * PITCH;        // elements per image
+    constexpr int F4 = K / 16;               // float4 per thread and row (4 threads per row); the first F4/2 belong to pass 0
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16* xs = reinterpret_cast<bf16*>(smem_raw);                                        // [3][128][PITCH]: h, m, l of the current K half
+    float* s_gb = reinterpret_cast<float*>(smem_raw + (size_t)3 * IMG * sizeof(bf16));  // [2][K] LN gamma / beta
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.y * ROWS;
+    if (p.ts && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ts_put(p.ts, p.ts_id, 2);
+    const int nrows = min(ROWS, p.B - row0);
+    int n0[2];
+    bool have[2];
+    const float* wp[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int t = w + 8 * nb;
+        n0[nb] = (blockIdx.x * CT + t) * 16;
+        have[nb] = __builtin_amdgcn_readfirstlane((int)(t < CT && n0[nb] < p.N)) != 0;
+        int wr = n0[nb] + r16;
+        wr = wr < p.N ? wr : p.N - 1;
+        wp[nb] = (const float*)p.W + (size_t)wr * K + g * 8;
+    }
+    if (!have[1]) wp[1] = wp[0];
+    constexpr int NSL = 3 < 2 * KSH ? 3 : 2 * KSH;  // weight-fragment register sets per tile: k-step kk lives in set kk % NSL and, once
+    f32x8 wf[2][NSL];                                // split, the set is refilled with k-step kk + NSL (across the pass boundary too)
+    auto wload = [&](int nb, int ks) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wp[nb] + ks * 32), b = *reinterpret_cast<const f32x4*>(wp[nb] + ks * 32 + 4);
+        return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    };
+    float mk[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // staging role: row lr = thread / 4, quarter q4 = thread % 4; the thread owns float4 indices q4 + 4 j (j < F4) of its row
+    const int lr = threadIdx.x >> 2, q4 = threadIdx.x & 3;
+    const float* xr = p.x + (size_t)(row0 + min(lr, nrows - 1)) * p.ldx;
+    float mean, rstd;
+    auto stage = [&](const f32x4 (&v)[F4 / 2], int pass) {  // normalise + split the pass's F4/2 float4 of this thread -> LDS
+#pragma unroll
+        for (int j = 0; j < F4 / 2; ++j) {
+            const int k = 4 * (q4 + 4 * (pass * (F4 / 2) + j));  // column of the row
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(s_gb + k), bt = *reinterpret_cast<const f32x4*>(s_gb + K + k);
+            typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+            u16x4 oh, om, ol;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y = (v[j][e] - mean) * rstd * gm[e] + bt[e];
+                const unsigned uh = __float_as_uint(y) & 0xffff0000u;
+                const float r1 = y - __uint_as_float(uh);
+                const unsigned um = __float_as_uint(r1) & 0xffff0000u;
+                const float r2 = r1 - __uint_as_float(um);
+                oh[e] = (unsigned short)(uh >> 16);
+                om[e] = (unsigned short)(um >> 16);
+                ol[e] = (unsigned short)(__float_as_uint(r2) >> 16);
+            }
+            const int kc = k - pass * KH;  // column inside the pass's image
+            *reinterpret_cast<u16x4*>(&xs[lr * PITCH + kc]) = oh;
+            *reinterpret_cast<u16x4*>(&xs[IMG + lr * PITCH + kc]) = om;
+            *reinterpret_cast<u16x4*>(&xs[2 * IMG + lr * PITCH + kc]) = ol;
+        }
+    };
+    {  // pass 0: the whole row for the statistics, its first half staged
+        f32x4 v0[F4 / 2], v1[F4 / 2];
+#pragma unroll
+        for (int j = 0; j < F4 / 2; ++j) {
+            v0[j] = *reinterpret_cast<const f32x4*>(xr + 4 * (q4 + 4 * j));
+            v1[j] = *reinterpret_cast<const f32x4*>(xr + 4 * (q4 + 4 * (F4 / 2 + j)));
+        }
+        f32x4 gbv = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int gi = threadIdx.x;  // float4 index into [gamma | beta]
+        if (gi < K / 2) gbv = *reinterpret_cast<const f32x4*>((gi < K / 4 ? p.ln_g : p.ln_b - K) + 4 * gi);
+        if (p.amax_mask) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mk[nb][r] = p.amax_mask[min(n0[nb] + g * 4 + r, p.N - 1)];
+        }
+        if (gi < K / 2) *reinterpret_cast<f32x4*>(s_gb + 4 * gi) = gbv;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) wf[0][i] = wload(0, i);
+        // one-pass statistics in the order of the 8-threads-per-row scheme: virtual thread q owns float4 q + 8 i.  This thread's
+        // float4 j is index q4 + 4 j: even j -> virtual thread q4 (i = j / 2), odd j -> virtual thread q4 + 4.
+        float sa = 0.f, qa = 0.f, sb = 0.f, qb = 0.f;
+        static_assert((F4 / 2) % 2 == 0, "the parity of a float4's index is the same in both halves");
+        auto accum = [&](const f32x4 (&v)[F4 / 2]) {
+#pragma unroll
+            for (int j = 0; j < F4 / 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (j & 1) {
+                        sb += v[j][e];
+                        qb += v[j][e] * v[j][e];
+                    } else {
+                        sa += v[j][e];
+                        qa += v[j][e] * v[j][e];
+                    }
+                }
+        };
+        accum(v0);
+        accum(v1);
+#pragma unroll
+        for (int o = 1; o <= 2; o <<= 1) {  // the butterfly's first two levels, inside each half of the 8 virtual threads
+            sa += __shfl_xor(sa, o, 64);
+            qa += __shfl_xor(qa, o, 64);
+            sb += __shfl_xor(sb, o, 64);
+            qb += __shfl_xor(qb, o, 64);
+        }
+        const float sm = sa + sb, sq = qa + qb;  // its last level
+        mean = sm / (float)K;
+        const float var = (sq / (float)K) - (mean * mean);
+        rstd = 1.0f / sqrtf(var + 1e-5f);
+        stage(v0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) wf[1][i] = wload(1, i);
+    f32x4 acc[2][NRB];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc[nb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto restage = [&]() {  // every wave, tiles or not: the second K half of the rows
+        __syncthreads();  // all fragment reads of the first half are done
+        f32x4 v1[F4 / 2];
+#pragma unroll
+        for (int j = 0; j < F4 / 2; ++j) v1[j] = *reinterpret_cast<const f32x4*>(xr + 4 * (q4 + 4 * (F4 / 2 + j)));
+        stage(v1, 1);
+        __syncthreads();
+    };
+    auto run = [&](auto NB) {
+        constexpr int nbn = decltype(NB)::value;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) restage();
+            if constexpr (nbn > 0) {
+#pragma unroll
+                for (int i = 0; i < KSH; ++i) {
+                    Split3 ws[nbn];
+#pragma unroll
+                    for (int nb = 0; nb < nbn; ++nb) {
+                        constexpr int dummy = 0;
+                        (void)dummy;
+                        const int kk = pass * KSH + i;  // compile-time after unrolling
+                        ws[nb] = split3(wf[nb][kk % NSL]);
+                        if (kk + NSL < 2 * KSH) wf[nb][kk % NSL] = wload(nb, kk + NSL);  // rolling: the set just split takes k-step kk + NSL
+                    }
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) {
+                        const int xo = (rb * 16 + r16) * PITCH + i * 32 + g * 8;
+                        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(&xs[xo]);
+                        const bf16x8 xm = *reinterpret_cast<const bf16x8*>(&xs[IMG + xo]);
+                        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(&xs[2 * IMG + xo]);
+#pragma unroll
+                        for (int nb = 0; nb < nbn; ++nb) {  // smallest terms first, as the 64-row kernel
+                            f32x4 a = acc[nb][rb];
+                            a = mma_bf16(ws[nb].l, xh, a);
+                            a = mma_bf16(ws[nb].h, xl, a);
+                            a = mma_bf16(ws[nb].m, xm, a);
+                            a = mma_bf16(ws[nb].m, xh, a);
+                            a = mma_bf16(ws[nb].h, xm, a);
+                            a = mma_bf16(ws[nb].h, xh, a);
+                            acc[nb][rb] = a;
+                        }
+                    }
+                }
+            }
+        }
+    };
+    if (have[1])
+        run(std::integral_constant<int, 2>{});
+    else if (have[0])
+        run(std::integral_constant<int, 1>{});
+    else
+        run(std::integral_constant<int, 0>{});
+    __syncthreads();  // the epilogue's scratch overlays the activation images
+    static_assert(LogitsScratch<NRB>::bytes <= (size_t)3 * IMG * sizeof(bf16), "epilogue scratch must fit the activation images");
+    logits_epilogue<NRB>(p, CT, acc, n0, have, mk, row0, nrows, lane, w, LogitsScratch<NRB>::carve(smem_raw));
+}
+template <int KD> static int launch_dec_logits_split128_t(const DecLinearParams& p, hipStream_t st) {
+    const size_t lds = (size_t)3 * 128 * (KD * 64 + 16) * sizeof(bf16) + (size_t)2 * KD * 128 * sizeof(float);
+    if (lds > 48 * 1024)
+        if (const hipError_t e = ensure_dyn_lds<&dec_logits_split128_kernel<KD>>((int)lds); e != hipSuccess)
+            return launch_hip_failed("logits kernel (split fp32, 128 rows): dynamic LDS attribute", e);
+    const int ct = dec_logits_tiles_per_wg(p.N);
+    dim3 grid(dec_logits_parts(p.N), (p.B + 127) / 128);
+    hipLaunchKernelGGL((dec_logits_split128_kernel<KD>), grid, dim3(512), lds, st, p, ct);
+    return WM_LAUNCH_OK;
+}
 template <int KD, int NRB> static int launch_dec_logits_split_t(const DecLinearParams& p, hipStream_t st) {
     const size_t lds = (size_t)3 * NRB * 16 * (KD * 128 + 16) * sizeof(bf16) + (size_t)2 * KD * 128 * sizeof(float);
     if (lds > 48 * 1024)
@@ -912,6 +1112,9 @@ template <typename TW> int launch_dec_logits(const DecLinearParams& p, hipStream
         static const bool exact = wm_env("WM_LOGITS_EXACT") != nullptr;
         if (!exact && (kd == 1 || kd == 3)) {
             if (p.B <= 16) return kd == 1 ? launch_dec_logits_split_t<1, 1>(p, st) : launch_dec_logits_split_t<3, 1>(p, st);
+            // more than 64 rows (coalesced batches): 128 rows per workgroup, the embedding streamed once per 128 (WM_LOGITS_NO128: A/B)
+            static const bool no128 = wm_env("WM_LOGITS_NO128") != nullptr;
+            if (p.B > 64 && !no128) return kd == 1 ? launch_dec_logits_split128_t<1>(p, st) : launch_dec_logits_split128_t<3>(p, st);
             return kd == 1 ? launch_dec_logits_split_t<1, 4>(p, st) : launch_dec_logits_split_t<3, 4>(p, st);
         }
     }
