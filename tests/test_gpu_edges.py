@@ -230,9 +230,11 @@ def test_coalesced_submits_return_each_batch_its_own_ids(hip, micro_cfg, micro_w
     plain.close()
 
 
-def test_coalesced_tiny_b64_pairs_equal_uncoalesced(hip, tiny_cfg, tiny_weights):
-    """The benched form: BASELINE config 3 as written (bf16 encoder, fp32 decoder + KV), 64 clips per submit, coalesce = 2, four
-    submits in flight = two 128-row passes.  Each submit's ids equal the uncoalesced model's, bit for bit, all 64 rows."""
+@pytest.mark.parametrize("dec_fp32", [True, False])
+def test_coalesced_tiny_b64_pairs_equal_uncoalesced(hip, tiny_cfg, tiny_weights, dec_fp32):
+    """The benched form: BASELINE config 3 as written (bf16 encoder, fp32 decoder + KV) — and the all-16-bit variant —, 64 clips per
+    submit, coalesce = 2, four submits in flight = two 128-row passes (128-row logits kernels).  Each submit's ids equal the
+    uncoalesced model's, bit for bit, all 64 rows."""
     import ctypes as C
     from whisper_mojo_amd import _lib
     L = _lib.lib()
@@ -240,10 +242,11 @@ def test_coalesced_tiny_b64_pairs_equal_uncoalesced(hip, tiny_cfg, tiny_weights)
     for i in range(128):
         L.wm_synth_mel_host(1000 + i, 80, 3000, mels[i].ctypes.data_as(C.POINTER(C.c_float)))
     kw = dict(max_loop=30, ignore_eot=True)
-    plain = make_model(tiny_cfg, tiny_weights, compute_dtype=1, kv_dtype=0, max_batch=64, decoder_fp32=True)
+    mk = dict(compute_dtype=1, kv_dtype=0 if dec_fp32 else 1, max_batch=64, decoder_fp32=dec_fp32)
+    plain = make_model(tiny_cfg, tiny_weights, **mk)
     want = [plain.transcribe_batch(mels[:64], **kw), plain.transcribe_batch(mels[64:], **kw)]
     plain.close()
-    m = make_model(tiny_cfg, tiny_weights, compute_dtype=1, kv_dtype=0, max_batch=64, decoder_fp32=True, coalesce=2)
+    m = make_model(tiny_cfg, tiny_weights, coalesce=2, **mk)
     for slot, half in ((0, 0), (1, 1), (2, 1), (3, 0)):
         m.transcribe_submit(mels[64 * half:64 * half + 64], slot=slot, **kw)
     assert m.transcribe_wait(0) == want[0] and m.transcribe_wait(1) == want[1]
@@ -251,20 +254,21 @@ def test_coalesced_tiny_b64_pairs_equal_uncoalesced(hip, tiny_cfg, tiny_weights)
     m.close()
 
 
-def test_logits_128_row_kernel_equals_64_row_kernel(hip, micro_cfg, micro_weights):
+@pytest.mark.parametrize("dtype", [0, 1, 2])
+def test_logits_128_row_kernel_equals_64_row_kernel(hip, micro_cfg, micro_weights, dtype):
     """Decode states of more than 64 rows take the 128-rows-per-workgroup logits kernel (fp32 decoder: two K passes over three
     bf16 images; LayerNorm statistics summed in the 64-row kernel's order).  Its ids must equal the 64-row kernel's bit for
     bit: B = 80 in one state against the same utterances in batches of 40 (64-row kernel), and 40 + 40 coalesced."""
     from whisper_mojo_amd import synth
     mels = synth.synth_mels(micro_cfg, 300, 80)
     kw = dict(prompt=(1, 2, 3, 4), eot=-1, max_loop=24)
-    small = make_model(micro_cfg, micro_weights, max_batch=40)
+    small = make_model(micro_cfg, micro_weights, compute_dtype=dtype, max_batch=40)
     want = small.transcribe_batch(mels[:40], **kw) + small.transcribe_batch(mels[40:], **kw)
     small.close()
-    big = make_model(micro_cfg, micro_weights, max_batch=80)
+    big = make_model(micro_cfg, micro_weights, compute_dtype=dtype, max_batch=80)
     assert big.transcribe_batch(mels, **kw) == want
     big.close()
-    pair = make_model(micro_cfg, micro_weights, max_batch=40, coalesce=2)
+    pair = make_model(micro_cfg, micro_weights, compute_dtype=dtype, max_batch=40, coalesce=2)
     pair.transcribe_submit(mels[:40], slot=0, **kw)
     pair.transcribe_submit(mels[40:], slot=1, **kw)
     assert pair.transcribe_wait(0) + pair.transcribe_wait(1) == want

@@ -4,7 +4,7 @@ sys.path.insert(0, os.getcwd())
 from whisper_mojo_amd import WhisperConfig, _lib, DT_BF16
 from whisper_mojo_amd.loader import WeightLoader
 from whisper_mojo_amd.whisper import Whisper
-L = _lib.lib(); cfg = WhisperConfig.tiny(); B = 64
+L = _lib.lib(); cfg = WhisperConfig.tiny(); B = int(os.environ.get('WM_PHASES_B', '64'))
 w = np.empty(cfg.weight_count(), np.float32); d = cfg.dims()
 L.wm_synth_weights(C.byref(d), 0, w.ctypes.data_as(C.POINTER(C.c_float)))
 mel = np.empty((B, 80, 3000), np.float32)

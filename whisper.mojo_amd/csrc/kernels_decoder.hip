@@ -639,7 +639,7 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
     else if (have[0])
         body(std::integral_constant<int, 1>{});
     WM_LG_STAMP(3);
-    {
+    if constexpr (NRB <= 4) {
         __shared__ float s_av[8 * 4][NRB * 16];
         __shared__ int s_ai[8 * 4][NRB * 16];
         __shared__ float s_tv[8][NRB * 16], s_tm[8][NRB * 16], s_ts[8][NRB * 16];
@@ -652,6 +652,10 @@ __global__ __launch_bounds__(512) void dec_logits_kernel(DecLinearParams p, int 
         sc.ts = s_ts;
         sc.ti = s_ti;
         logits_epilogue<NRB>(p, CT, acc, n0, have, mk, row0, nrows, lane, w, sc);
+    } else {  // 128 rows: the 48 KB of scratch do not fit beside the activation image — overlay it once every wave is done reading
+        __syncthreads();
+        static_assert(LogitsScratch<NRB>::bytes <= (size_t)NRB * 16 * PITCH * sizeof(TW), "epilogue scratch must fit the activation image");
+        logits_epilogue<NRB>(p, CT, acc, n0, have, mk, row0, nrows, lane, w, LogitsScratch<NRB>::carve(smem_raw));
     }
     WM_LG_STAMP(4);
 }
@@ -891,6 +895,12 @@ __global__ __launch_bounds__(512) void dec_logits_split128_kernel(DecLinearParam
     const int r16 = lane & 15, g = lane >> 4;
     const int row0 = blockIdx.y * ROWS;
     if (p.ts && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ts_put(p.ts, p.ts_id, 2);
+#ifdef WM_DEV  // phase stamps (wm_bench_kernel id 40): 0 entry, 1 first half staged, 2 past its barrier, 5 first half multiplied, 6 second half staged, 3 all multiplied, 4 end
+#define WM_LG_STAMP(k) do { if (p.dbg && (threadIdx.x & 63) == 0) p.dbg[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define WM_LG_STAMP(k) do { } while (0)
+#endif
+    WM_LG_STAMP(0);
     const int nrows = min(ROWS, p.B - row0);
     int n0[2];
     bool have[2];
@@ -907,7 +917,7 @@ __global__ __launch_bounds__(512) void dec_logits_split128_kernel(DecLinearParam
     if (!have[1]) wp[1] = wp[0];
     constexpr int NSL = 3 < 2 * KSH ? 3 : 2 * KSH;  // weight-fragment register sets per tile: k-step kk lives in set kk % NSL and, once
     f32x8 wf[2][NSL];                                // split, the set is refilled with k-step kk + NSL (across the pass boundary too)
-    auto wload = [&](int nb, int ks) {
+    auto wload = [&](int nb, int ks) __attribute__((always_inline)) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(wp[nb] + ks * 32), b = *reinterpret_cast<const f32x4*>(wp[nb] + ks * 32 + 4);
         return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     };
@@ -916,7 +926,7 @@ __global__ __launch_bounds__(512) void dec_logits_split128_kernel(DecLinearParam
     const int lr = threadIdx.x >> 2, q4 = threadIdx.x & 3;
     const float* xr = p.x + (size_t)(row0 + min(lr, nrows - 1)) * p.ldx;
     float mean, rstd;
-    auto stage = [&](const f32x4 (&v)[F4 / 2], int pass) {  // normalise + split the pass's F4/2 float4 of this thread -> LDS
+    auto stage = [&](const f32x4 (&v)[F4 / 2], int pass) __attribute__((always_inline)) {  // normalise + split the pass's F4/2 float4 of this thread -> LDS
 #pragma unroll
         for (int j = 0; j < F4 / 2; ++j) {
             const int k = 4 * (q4 + 4 * (pass * (F4 / 2) + j));  // column of the row
@@ -964,7 +974,7 @@ __global__ __launch_bounds__(512) void dec_logits_split128_kernel(DecLinearParam
         // float4 j is index q4 + 4 j: even j -> virtual thread q4 (i = j / 2), odd j -> virtual thread q4 + 4.
         float sa = 0.f, qa = 0.f, sb = 0.f, qb = 0.f;
         static_assert((F4 / 2) % 2 == 0, "the parity of a float4's index is the same in both halves");
-        auto accum = [&](const f32x4 (&v)[F4 / 2]) {
+        auto accum = [&](const f32x4 (&v)[F4 / 2]) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < F4 / 2; ++j)
 #pragma unroll
@@ -993,7 +1003,9 @@ __global__ __launch_bounds__(512) void dec_logits_split128_kernel(DecLinearParam
         rstd = 1.0f / sqrtf(var + 1e-5f);
         stage(v0, 0);
     }
+    WM_LG_STAMP(1);
     __syncthreads();
+    WM_LG_STAMP(2);
 #pragma unroll
     for (int i = 0; i < NSL; ++i) wf[1][i] = wload(1, i);
     f32x4 acc[2][NRB];
@@ -1001,7 +1013,7 @@ __global__ __launch_bounds__(512) void dec_logits_split128_kernel(DecLinearParam
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) acc[nb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto restage = [&]() {  // every wave, tiles or not: the second K half of the rows
+    auto restage = [&]() __attribute__((always_inline)) {  // every wave, tiles or not: the second K half of the rows
         __syncthreads();  // all fragment reads of the first half are done
         f32x4 v1[F4 / 2];
 #pragma unroll
@@ -1009,11 +1021,15 @@ __global__ __launch_bounds__(512) void dec_logits_split128_kernel(DecLinearParam
         stage(v1, 1);
         __syncthreads();
     };
-    auto run = [&](auto NB) {
+    auto run = [&](auto NB) __attribute__((always_inline)) {
         constexpr int nbn = decltype(NB)::value;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
-            if (pass == 1) restage();
+            if (pass == 1) {
+                WM_LG_STAMP(5);
+                restage();
+                WM_LG_STAMP(6);
+            }
             if constexpr (nbn > 0) {
 #pragma unroll
                 for (int i = 0; i < KSH; ++i) {
@@ -1026,23 +1042,29 @@ __global__ __launch_bounds__(512) void dec_logits_split128_kernel(DecLinearParam
                         ws[nb] = split3(wf[nb][kk % NSL]);
                         if (kk + NSL < 2 * KSH) wf[nb][kk % NSL] = wload(nb, kk + NSL);  // rolling: the set just split takes k-step kk + NSL
                     }
+                    // Row blocks in pairs, the six products of a k-step interleaved over the pair's (and both tiles') accumulators: 128
+                    // rows make this kernel MFMA-bound, and six back-to-back MFMAs on ONE accumulator wait for each other's results.
+                    // Per accumulator the order of the six terms is the 64-row kernel's (smallest first).
 #pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb) {
-                        const int xo = (rb * 16 + r16) * PITCH + i * 32 + g * 8;
-                        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(&xs[xo]);
-                        const bf16x8 xm = *reinterpret_cast<const bf16x8*>(&xs[IMG + xo]);
-                        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(&xs[2 * IMG + xo]);
+                    for (int rp = 0; rp < NRB; rp += 2) {
+                        bf16x8 xh[2], xm[2], xl[2];
 #pragma unroll
-                        for (int nb = 0; nb < nbn; ++nb) {  // smallest terms first, as the 64-row kernel
-                            f32x4 a = acc[nb][rb];
-                            a = mma_bf16(ws[nb].l, xh, a);
-                            a = mma_bf16(ws[nb].h, xl, a);
-                            a = mma_bf16(ws[nb].m, xm, a);
-                            a = mma_bf16(ws[nb].m, xh, a);
-                            a = mma_bf16(ws[nb].h, xm, a);
-                            a = mma_bf16(ws[nb].h, xh, a);
-                            acc[nb][rb] = a;
+                        for (int r = 0; r < 2; ++r) {
+                            const int xo = ((rp + r) * 16 + r16) * PITCH + i * 32 + g * 8;
+                            xh[r] = *reinterpret_cast<const bf16x8*>(&xs[xo]);
+                            xm[r] = *reinterpret_cast<const bf16x8*>(&xs[IMG + xo]);
+                            xl[r] = *reinterpret_cast<const bf16x8*>(&xs[2 * IMG + xo]);
                         }
+#define WM_TERM(WPART, XPART)                                                                            \
+    _Pragma("unroll") for (int r = 0; r < 2; ++r) _Pragma("unroll") for (int nb = 0; nb < nbn; ++nb)     \
+        acc[nb][rp + r] = mma_bf16(ws[nb].WPART, XPART[r], acc[nb][rp + r]);
+                        WM_TERM(l, xh)
+                        WM_TERM(h, xl)
+                        WM_TERM(m, xm)
+                        WM_TERM(m, xh)
+                        WM_TERM(h, xm)
+                        WM_TERM(h, xh)
+#undef WM_TERM
                     }
                 }
             }
@@ -1054,10 +1076,13 @@ __global__ __launch_bounds__(512) void dec_logits_split128_kernel(DecLinearParam
         run(std::integral_constant<int, 1>{});
     else
         run(std::integral_constant<int, 0>{});
+    WM_LG_STAMP(3);
     __syncthreads();  // the epilogue's scratch overlays the activation images
     static_assert(LogitsScratch<NRB>::bytes <= (size_t)3 * IMG * sizeof(bf16), "epilogue scratch must fit the activation images");
     logits_epilogue<NRB>(p, CT, acc, n0, have, mk, row0, nrows, lane, w, LogitsScratch<NRB>::carve(smem_raw));
+    WM_LG_STAMP(4);
 }
+#undef WM_LG_STAMP
 template <int KD> static int launch_dec_logits_split128_t(const DecLinearParams& p, hipStream_t st) {
     const size_t lds = (size_t)3 * 128 * (KD * 64 + 16) * sizeof(bf16) + (size_t)2 * KD * 128 * sizeof(float);
     if (lds > 48 * 1024)
@@ -1122,6 +1147,16 @@ template <typename TW> int launch_dec_logits(const DecLinearParams& p, hipStream
         if (kd == 1) return launch_dec_logits_t<TW, 1, 1>(p, st);
         if (kd == 3) return launch_dec_logits_t<TW, 3, 1>(p, st);
         return launch_dec_logits_t<TW, 4, 1>(p, st);
+    }
+    if constexpr (sizeof(TW) == 2) {
+        // more than 64 rows (coalesced batches): 128 rows per workgroup — the embedding is streamed once per 128 rows, not per 64
+        // (every row's arithmetic is the 64-row instantiation's: same staging threads per row, same k order)
+        static const bool no128 = wm_env("WM_LOGITS_NO128") != nullptr;
+        if (p.B > 64 && !no128) {
+            if (kd == 1) return launch_dec_logits_t<TW, 1, 8>(p, st);
+            if (kd == 3) return launch_dec_logits_t<TW, 3, 8>(p, st);
+            return launch_dec_logits_t<TW, 4, 8>(p, st);
+        }
     }
     if (kd == 1) return launch_dec_logits_t<TW, 1, 4>(p, st);
     if (kd == 3) return launch_dec_logits_t<TW, 3, 4>(p, st);
