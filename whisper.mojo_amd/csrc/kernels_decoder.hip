@@ -1148,16 +1148,20 @@ template <typename TW> int launch_dec_logits(const DecLinearParams& p, hipStream
         if (kd == 3) return launch_dec_logits_t<TW, 3, 1>(p, st);
         return launch_dec_logits_t<TW, 4, 1>(p, st);
     }
+#ifdef WM_DEV
     if constexpr (sizeof(TW) == 2) {
-        // more than 64 rows (coalesced batches): 128 rows per workgroup — the embedding is streamed once per 128 rows, not per 64
-        // (every row's arithmetic is the 64-row instantiation's: same staging threads per row, same k order)
-        static const bool no128 = wm_env("WM_LOGITS_NO128") != nullptr;
-        if (p.B > 64 && !no128) {
+        // Developer A/B (WM_LOGITS_128_16BIT): 128 rows per workgroup for 16-bit weights too.  Measured SLOWER than two 64-row
+        // launches (tiny bf16, coalesced pairs: 16.5 vs 15.8 ms per pass; base f16: equal): the second launch's 40 MB embedding
+        // stream is served by the Infinity Cache, so there is no HBM traffic to save, and the 128-row form stages and reduces twice
+        // the rows behind one stream.  The fp32 form (80 MB per stream, MFMA-heavy) does gain: dec_logits_split128_kernel.
+        static const bool on128 = wm_env("WM_LOGITS_128_16BIT") != nullptr;
+        if (p.B > 64 && on128) {
             if (kd == 1) return launch_dec_logits_t<TW, 1, 8>(p, st);
             if (kd == 3) return launch_dec_logits_t<TW, 3, 8>(p, st);
             return launch_dec_logits_t<TW, 4, 8>(p, st);
         }
     }
+#endif
     if (kd == 1) return launch_dec_logits_t<TW, 1, 4>(p, st);
     if (kd == 3) return launch_dec_logits_t<TW, 3, 4>(p, st);
     return launch_dec_logits_t<TW, 4, 4>(p, st);
