@@ -14,7 +14,12 @@ already resident in HBM.  Rank 0 prints ONE JSON line.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W        # BASELINE config 4 at N=8
 
+Protocol of the timed region: K full passes of 64 clips per GPU, issued in groups of `config.pipeline_depth` = 8 through the
+library's pipeline slots (submit the group, collect the group, all-gather the group when N > 1); with `--coalesce 2` (default) the
+library pairs consecutive submits into one 128-row decode state — every submit still is B = 64 and receives exactly its own ids.
+
 Besides the contract's keys the line carries (all timed in this same run, N = 1 only):
+  value_uncoalesced  the same passes with one decode state per submit, four in flight (round 2's protocol) and the ratio
   value_with_h2d     the same K steps with the 61 MB of mels uploaded from pinned host memory INSIDE the timed region
                      (SURVEY §8d's literal timed region; `value` keeps the mels resident, as the bench contract asks)
   unpipelined        the K steps strictly one after another
