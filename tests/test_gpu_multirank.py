@@ -107,7 +107,7 @@ def test_device_gather_buffer_and_rccl_world_of_one(hip, tmp_path):
     (wm_transcribe_wait_device), a process group of ONE rank on backend "nccl" (RCCL initialises, all_gather_into_tensor runs on
     the device buffer), against the host path of a plain run: same ids."""
     dev, host = str(tmp_path / "dev.npy"), str(tmp_path / "host.npy")
-    r1 = _bench(1, 16, dev, {"WM_BENCH_DEVICE_GATHER": "1"})
+    r1 = _bench(1, 16, dev, {"WM_BENCH_DEVICE_GATHER": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
     r0 = _bench(1, 16, host, {})
     assert r1["n_gpus"] == 1
     a, b = np.load(host), np.load(dev)
