@@ -268,6 +268,11 @@ def test_logits_128_row_kernel_equals_64_row_kernel(hip, micro_cfg, micro_weight
     big = make_model(micro_cfg, micro_weights, compute_dtype=dtype, max_batch=80)
     assert big.transcribe_batch(mels, **kw) == want
     big.close()
+    if dtype == 0:  # two row blocks of the 128-row kernel, the second one ragged (150 = 128 + 22 rows)
+        more = np.concatenate([mels, mels[:70]])
+        huge = make_model(micro_cfg, micro_weights, compute_dtype=dtype, max_batch=150)
+        assert huge.transcribe_batch(more, **kw) == want + want[:70]
+        huge.close()
     pair = make_model(micro_cfg, micro_weights, compute_dtype=dtype, max_batch=40, coalesce=2)
     pair.transcribe_submit(mels[:40], slot=0, **kw)
     pair.transcribe_submit(mels[40:], slot=1, **kw)
