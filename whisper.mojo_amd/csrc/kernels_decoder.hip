@@ -1107,6 +1107,10 @@ template <int KD, int NRB> static int launch_dec_logits_split_t(const DecLinearP
 // column tiles (of 16) per workgroup: the smallest count that covers the vocabulary with <= 256 workgroups, at most 16
 int dec_logits_tiles_per_wg(int N) {
     const int tiles = (N + 15) / 16;
+    // (developer A/B WM_LOGITS_CT: 14 / 16 tiles per workgroup — every wave two tiles at 16 — measured the same launch time as 13:
+    //  the stream's end is set by the chip-wide rate, not by the busiest wave)
+    static const int ct_env = wm_env("WM_LOGITS_CT") ? atoi(wm_env("WM_LOGITS_CT")) : 0;
+    if (ct_env > 0 && tiles > 16) return std::max((tiles + 255) / 256, std::min(16, ct_env));
     return std::max(1, std::min(16, (tiles + 255) / 256));
 }
 int dec_logits_ids_per_part(int N) { return dec_logits_tiles_per_wg(N) * 16; }
