@@ -107,6 +107,7 @@ def test_tiny_fp32_195_steps_five_utterances(hip, oracle_mod, tiny_cfg, tiny_wei
     lg = teacher_forced(m, cache, streams, 4)
     assert lg.shape[0] == 196 and cache.current_len == 199
     err = max(np.abs(lg[:, b] - wlog[b]).max() for b in range(len(seeds)))
+    print(f"tiny fp32, 5 clips x 196 positions x 51 865 logits (split-bf16 logits kernel): max |logit - oracle| = {err:.2e}")
     assert err < F32_TOL, err
     for b in range(len(seeds)):
         clear = margins_of(wlog[b]) > MARGIN_TOL
