@@ -673,7 +673,7 @@ int dec_logits_parts(int N);
 // — six v_mfma_f32_16x16x32_bf16 (16 cycles each, K = 32) instead of eight fp32 MFMAs of K = 4 (32 cycles each): 96 against 256
 // cycles per 16x16x32 block.  The three dropped terms (wm·xl, wl·xm, wl·xl) are < 2^-21 |w·x| together in the worst case
 // (truncation leaves |m| < 2^-7 |x|, |l| < 2^-15 |x|), 2^-24 typically; accumulation stays fp32.  Measured over 5 clips x 196
-// positions x 51 865 logits: max |logit - oracle| 5.3e-6, against 6.3e-6 for the exact-fp32 MFMA kernel (tests/test_split3.py
+// positions x 51 865 logits: largest deviation from the fp32 CPU restatement 5.3e-6, against 6.3e-6 for the exact-fp32 MFMA kernel (tests/test_split3.py
 // restates the arithmetic; tests/test_gpu_long_parity.py prints the figure).  The weights are split in registers as they arrive (44 VALU operations per fragment, hidden in
 // the MFMAs' issue gaps); the normalised activations are split ONCE per workgroup and parked in LDS as three bf16 images.
 struct Split3 {
